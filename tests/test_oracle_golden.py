@@ -1,0 +1,214 @@
+"""Pin the oracle (oracle/aurora_oracle.py + oracle/tome_ref.c) against the golden vectors that
+were produced by the reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aurora_oracle as O
+from oracle import tome_ref
+from tests.util import cfg_of, enc_layers, golden, sub, tt
+
+
+def test_g1_schedule_table():
+    tab = golden("g1_schedule.npz")["table"]
+    for L, ratio, r, kept in tab:
+        L = int(L)
+        assert O.tome_r(378, 378, 14, float(ratio), L) == int(r)
+        assert O.kept_tokens(378, 378, 14, float(ratio), L) == int(kept)
+    # the SURVEY section-8 table (L=32): bold BASELINE configs
+    assert O.kept_tokens(378, 378, 14, 0.3, 32) == 264
+    assert O.kept_tokens(378, 378, 14, 0.2, 32) == 171
+    assert O.kept_tokens(378, 378, 14, 0.8, 32) == 605
+    assert O.tome_r(378, 378, 14, 0.8, 32) == 4      # 1-0.8 = 0.19999999999999996 in doubles
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 5])
+def test_g2_tome_kat(r):
+    g = golden("g2_tome_kat.npz")
+    metric, x = tt(g["metric"]), tt(g["x"])
+    y, s, m = O.tome_step(metric, x, None, r)
+    np.testing.assert_array_equal(y.numpy(), g[f"r{r}_y"])
+    np.testing.assert_array_equal(s.numpy(), g[f"r{r}_size"])
+    for k in ("unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(m[k].numpy(), g[f"r{r}_{k}"])
+    # C oracle: same indices, same merged values
+    mc = tome_ref.match(g["metric"], r)
+    for k in ("unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(mc[k], g[f"r{r}_{k}"])
+    yc, sc = tome_ref.merge(g["x"], np.ones((1, 9), np.float32), mc)
+    np.testing.assert_array_equal(yc, g[f"r{r}_y"])
+    np.testing.assert_array_equal(sc[..., None], g[f"r{r}_size"])
+
+
+def test_g2_chain_and_g3_ties():
+    g = golden("g2_tome_kat.npz")
+    metric, x = tt(g["metric"]), tt(g["x"])
+    y1, s1, _ = O.tome_step(metric, x, None, 2)
+    y2, s2, _ = O.tome_step(y1, y1, s1, 2)
+    np.testing.assert_allclose(y2.numpy(), g["chain_y"], rtol=1e-6)
+    np.testing.assert_array_equal(s2.numpy(), g["chain_size"])
+    # tie rule: first maximum for argmax, lowest index first for selection
+    for impl in ("py", "c"):
+        if impl == "py":
+            m = O.bipartite_match(tt(g["tie_metric"]), 2)
+            got = {k: m[k].numpy() for k in ("unm_idx", "src_idx", "dst_idx")}
+        else:
+            got = tome_ref.match(g["tie_metric"], 2)
+        for k in ("unm_idx", "src_idx", "dst_idx"):
+            np.testing.assert_array_equal(got[k], g[f"tie_{k}"], err_msg=f"{impl}:{k}")
+
+
+@pytest.mark.parametrize("t,seed", [(730, 0), (265, 1), (606, 2)])
+@pytest.mark.parametrize("r", [4, 15, 18, 22])
+def test_g4_tome_path_shapes(t, seed, r):
+    g = golden("g4_tome_shapes.npz")
+    key = f"t{t}_r{r}"
+    gen = torch.Generator().manual_seed(int(g[key + "_seed"]))
+    metric = torch.randn(2, t, 80, generator=gen)
+    assert g[key + "_gaps"][:2].min() > 2e-6          # fixture avoids near-ties
+    m = O.bipartite_match(metric, r)
+    mc = tome_ref.match(metric.numpy(), r)
+    for k in ("unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(m[k].numpy(), g[f"{key}_{k}"], err_msg=k)
+        np.testing.assert_array_equal(mc[k], g[f"{key}_{k}"], err_msg="C:" + k)
+
+
+def test_g5_merge_wavg_sizes():
+    g = golden("g5_merge_wavg.npz")
+    metric, x, size = tt(g["metric"]), tt(g["x"]).float(), tt(g["size"])
+    y, s, m = O.tome_step(metric, x, size, 15)
+    np.testing.assert_array_equal(m["src_idx"].numpy(), g["src_idx"])
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(s.numpy(), g["size_out"])
+    mc = tome_ref.match(g["metric"], 15)
+    yc, sc = tome_ref.merge(x.numpy(), g["size"][..., 0], mc)
+    np.testing.assert_allclose(yc, g["y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(sc, g["size_out"][..., 0])
+
+
+@pytest.mark.parametrize("tag", ["tiny", "hd80"])
+def test_g6_attention(tag):
+    g = golden("g6_attention.npz")
+    lw = sub(g, f"{tag}.w.")
+    x, size = tt(g[f"{tag}.x"]), tt(g[f"{tag}.size"])
+    heads = int(g[f"{tag}.heads"])
+    o, metric = O.vit_attention(x, None, lw, heads)
+    np.testing.assert_allclose(o.numpy(), g[f"{tag}.out"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(metric.numpy(), g[f"{tag}.metric"], rtol=1e-5, atol=1e-6)
+    o2, _ = O.vit_attention(x, size, lw, heads)
+    np.testing.assert_allclose(o2.numpy(), g[f"{tag}.out_size"], rtol=1e-4, atol=2e-6)
+    # the proportional-attention term is a softmax no-op
+    assert np.abs(g[f"{tag}.out_size"] - g[f"{tag}.out"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["tiny", "gelu"])
+def test_g7_encoder_chain(tag):
+    g = golden("g7_encoder.npz")
+    cfg = cfg_of(g, f"{tag}.cfg")
+    layers = enc_layers(sub(g, f"{tag}.w."), cfg["L"])
+    hs = O.vit_encoder(tt(g[f"{tag}.x"]), layers, cfg["heads"], cfg["r"], cfg["act"])
+    if tag == "tiny":
+        assert [h.shape[1] for h in hs] == [17, 15, 13, 11, 9]
+        for i, h in enumerate(hs):
+            np.testing.assert_allclose(h.numpy(), g[f"tiny.hs{i}"], rtol=2e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(hs[-1].numpy(), g["gelu.hs_last"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(hs[-2].numpy(), g["gelu.hs_m2"], rtol=2e-4, atol=2e-5)
+
+
+def mid_encoder_weights(g):
+    """Re-create the seeded weights of the g7 'mid' encoder (recipe in make_golden.py)."""
+    cfg = cfg_of(g, "cfg")
+    names = json.loads(str(g["names"]))
+    D, inter = cfg["D"], cfg["inter"]
+    shapes = {}
+    for n in names:
+        leaf = n.split(".", 2)[2]
+        if leaf.endswith("weight"):
+            if "fc1" in leaf:
+                shapes[n] = (inter, D)
+            elif "fc2" in leaf:
+                shapes[n] = (D, inter)
+            elif "layer_norm" in leaf:
+                shapes[n] = (D,)
+            else:
+                shapes[n] = (D, D)
+        else:
+            shapes[n] = (inter,) if "fc1" in leaf else (D,)
+    gen = torch.Generator().manual_seed(cfg["wseed"])
+    flat = {}
+    for n in names:
+        if len(shapes[n]) == 2:
+            flat[n] = torch.randn(shapes[n], generator=gen) * 0.05
+    for n in names:
+        if len(shapes[n]) == 1:
+            if "layer_norm" in n and n.endswith("weight"):
+                flat[n] = 1.0 + 0.1 * torch.randn(shapes[n], generator=gen)
+            else:
+                flat[n] = 0.02 * torch.randn(shapes[n], generator=gen)
+    x = torch.randn(2, cfg["T"], D, generator=gen)
+    return cfg, enc_layers(flat, cfg["L"]), x
+
+
+def test_g7_encoder_mid_indices_and_rows():
+    g = golden("g7_encoder_mid.npz")
+    cfg, layers, x = mid_encoder_weights(g)
+    cap = []
+    hs = O.vit_encoder(x, layers, cfg["heads"], cfg["r"], cfg["act"], capture=cap)
+    np.testing.assert_array_equal([h.shape[1] for h in hs], g["counts"])
+    rows = np.array([0, 1, 2, 50, 100, 200, 264, -1])
+    for li, c in enumerate(cap):
+        for k in ("unm_idx", "src_idx", "dst_idx"):
+            np.testing.assert_array_equal(c["match"][k].numpy(), g[f"l{li}_{k}"], err_msg=f"layer {li} {k}")
+        # the C oracle agrees with the reference indices on the same metric
+        mc = tome_ref.match(c["metric"].numpy(), cfg["r"])
+        for k in ("unm_idx", "src_idx", "dst_idx"):
+            np.testing.assert_array_equal(mc[k], g[f"l{li}_{k}"], err_msg=f"C layer {li} {k}")
+    for i, h in enumerate(hs):
+        np.testing.assert_allclose(h[:, rows].numpy(), g[f"hs{i}_rows"], rtol=1e-3, atol=1e-4)
+
+
+def test_g8_projector_splice_and_constants():
+    g = golden("g8_projector_splice.npz")
+    pw = sub(g, "proj.")
+    vis = O.projector(tt(g["vis_in"]), pw)
+    np.testing.assert_allclose(vis.numpy(), g["vis"], rtol=1e-5, atol=1e-6)
+    emb = O.splice(tt(g["ids"])[0], tt(g["embed"]), tt(g["vis"]).view(2, 5, 96))
+    np.testing.assert_array_equal(emb.numpy(), g["inputs_embeds"][0])
+    assert emb.shape[0] == 16
+    assert str(g["vicuna_instruction"]) == O.VICUNA_INSTRUCTION
+    assert int(g["image_token_index"]) == O.IMAGE_TOKEN_INDEX
+    assert str(g["default_image_token"]) == O.DEFAULT_IMAGE_TOKEN
+
+
+def llama_weights(g):
+    flat = sub(g, "w.")
+    cfg = cfg_of(g, "cfg")
+    layers = []
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        layers.append({k[len(p):].replace("self_attn.", "").replace("mlp.", ""): v
+                       for k, v in flat.items() if k.startswith(p)})
+    lw = dict(layers=layers)
+    lw["norm.weight"] = flat["model.norm.weight"]
+    lw["embed_tokens.weight"] = flat["model.embed_tokens.weight"]
+    lw["lm_head.weight"] = flat["lm_head.weight"]
+    return lw, cfg
+
+
+def test_g9_llama_greedy_and_logits():
+    g = golden("g9_llama_tiny.npz")
+    lw, cfg = llama_weights(g)
+    ids, logits = O.llama_greedy(tt(g["embeds"])[0], lw, cfg, 8, eos_id=None, return_logits=True)
+    np.testing.assert_array_equal(ids, g["ids"][0])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-3, atol=2e-4)
+
+
+def test_process_text_and_prompt():
+    text = O.build_prompt("Describe the video in detail.", 3)
+    assert text == "USER: <image> <image> <image>\nDescribe the video in detail. ASSISTANT:"
+    enc = lambda s, special: ([1] if special else []) + [100 + len(s)]
+    ids = O.process_text(text, enc)
+    assert ids == [1, 106, -200, 101, -200, 101, -200, 141]
