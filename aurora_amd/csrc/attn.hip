@@ -1,0 +1,191 @@
+// Flash attention over operand fragments (ViT encoder attention and Llama causal prefill), gfx950.
+//
+// Reference: AuroraAttention.forward softmax(q k^T) v (aurora.py:647-688; the `+ size.log()` term at
+// :671-674 is a per-query-row constant, i.e. a softmax no-op - SURVEY fact 6 - and is not computed);
+// HF Llama causal SDPA for the prefill.
+//
+// Everything arrives in MFMA operand form, written by the QKV GEMM epilogue (gemm.hip):
+//   Q, K : [tok16][d-block][FRAG], rows = tokens, k-slots = d (PAIRED)  -> S^T = K Q^T
+//   V^T  : [d16][tok32][FRAG],     rows = d,      k-slots = tokens (PAIRED) -> O^T = V^T P^T
+// S^T accumulators (lane: 4 keys of one query) ARE the PAIRED-token B operand of the PV MFMA after a
+// cvt to fp16: the softmax and P never leave the lane's registers, there is no transpose and no LDS
+// traffic besides the lane-linear K/V fragment reads (ds_read_b128 at base + lane*16, conflict-free).
+// K/V tiles are staged by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per 64 keys.
+// A workgroup = 4 waves x 32 queries; each wave keeps 2 query tiles so every K/V fragment read feeds
+// two MFMAs.
+#include "kernels.h"
+
+template <int KBLK, int VD16>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    constexpr int NF = 4 * KBLK + 2 * VD16;       // fragments (KiB) per 64-key stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int qb = gridDim.x - 1 - blockIdx.x;     // heavy (late, causal) blocks first
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const KvLayout& kv = a.kv;
+    const int T16 = a.rows_per_seq >> 4, T32 = a.rows_per_seq >> 5;
+    const int q0 = qb * 128 + w * 32;
+
+    // Q fragments -> registers
+    h8 qf[2][KBLK];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int tq = (q0 >> 4) + qt;
+        tq = tq < T16 ? tq : T16 - 1;
+#pragma unroll
+        for (int b = 0; b < KBLK; ++b)
+            qf[qt][b] = *(const h8*)(a.Qf + ((((int64_t)seq * a.heads + head) * T16 + tq) * KBLK + b) * AUR_FRAG_HALVES + lane * 8);
+    }
+
+    int nkb = (a.t + 63) >> 6;
+    if (a.causal) {
+        const int lastq = qb * 128 + 127;
+        const int lim = (lastq >> 6) + 1;
+        nkb = nkb < lim ? nkb : lim;
+    }
+
+    auto stage = [&](int kb, int buf) {
+        char* dst = smem + buf * (NF * 1024);
+        for (int f = w; f < NF; f += 4) {
+            const half_t* src;
+            if (f < 4 * KBLK) {
+                int t16 = kb * 4 + f / KBLK;
+                t16 = t16 < T16 ? t16 : T16 - 1;
+                const int tok = t16 << 4;
+                src = kv_page(kv, a.seq0 + seq, tok) + kfrag_off(kv, head, (tok % kv.page_tokens) >> 4, f % KBLK);
+            } else {
+                const int fv = f - 4 * KBLK;
+                int t32 = kb * 2 + (fv & 1);
+                t32 = t32 < T32 ? t32 : T32 - 1;
+                const int tok = t32 << 5;
+                src = kv_page(kv, a.seq0 + seq, tok) + vfrag_off(kv, head, fv >> 1, (tok % kv.page_tokens) >> 5);
+            }
+            glds16(src + lane * 8, dst + f * 1024);
+        }
+    };
+
+    f4 acc_o[VD16][2];
+#pragma unroll
+    for (int d = 0; d < VD16; ++d)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) acc_o[d][qt] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float sc = a.scale * 1.4426950408889634f;
+
+    stage(0, 0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nkb) stage(kb + 1, (kb + 1) & 1);
+        const char* base = smem + (kb & 1) * (NF * 1024);
+
+        f4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt][0] = f4{0.f, 0.f, 0.f, 0.f};
+            s[kt][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < KBLK; ++b) {
+                const h8 kf = *(const h8*)(base + (kt * KBLK + b) * 1024 + lane * 16);
+                s[kt][0] = mfma16(kf, qf[0][b], s[kt][0]);
+                s[kt][1] = mfma16(kf, qf[1][b], s[kt][1]);
+            }
+        }
+        h8 pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int query = q0 + qt * 16 + c;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = kb * 64 + kt * 16 + 4 * g + i;
+                    const bool ok = key < a.t && (!a.causal || key <= query);
+                    const float v = ok ? s[kt][qt][i] * sc : -INFINITY;
+                    s[kt][qt][i] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
+            m_run[qt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(s[kt][qt][i] - m_use);
+                    ps += p;
+                    pf[qt][kt >> 1][(kt & 1) * 4 + i] = (half_t)p;
+                }
+            l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < VD16; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc_o[d][qt][i] *= alpha;
+        }
+#pragma unroll
+        for (int d = 0; d < VD16; ++d)
+#pragma unroll
+            for (int b32 = 0; b32 < 2; ++b32) {
+                const h8 vf = *(const h8*)(base + (4 * KBLK + d * 2 + b32) * 1024 + lane * 16);
+                acc_o[d][0] = mfma16(vf, pf[0][b32], acc_o[d][0]);
+                acc_o[d][1] = mfma16(vf, pf[1][b32], acc_o[d][1]);
+            }
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int query = q0 + qt * 16 + c;
+        if (query < a.rows_per_seq) {
+            half_t* orow = a.O + ((int64_t)seq * a.rows_per_seq + query) * a.ldo + head * a.hd + 4 * g;
+#pragma unroll
+            for (int d = 0; d < VD16; ++d) {
+                h4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc_o[d][qt][i] * inv);
+                *(h4*)(orow + d * 16) = o;
+            }
+        }
+    }
+}
+
+template <int KBLK, int VD16>
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * (4 * KBLK + 2 * VD16) * 1024;
+    dim3 grid((a.rows_per_seq + 127) / 128, a.heads, a.nseq);
+    hipLaunchKernelGGL((attn_kernel<KBLK, VD16>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int KBLK, int VD16>
+static hipError_t attn_init_t() {
+    return hipFuncSetAttribute((const void*)attn_kernel<KBLK, VD16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * (4 * KBLK + 2 * VD16) * 1024);
+}
+hipError_t attn_init() {
+    hipError_t e;
+    if ((e = attn_init_t<3, 5>()) != hipSuccess) return e;
+    if ((e = attn_init_t<4, 8>()) != hipSuccess) return e;
+    if ((e = attn_init_t<1, 1>()) != hipSuccess) return e;
+    if ((e = attn_init_t<1, 2>()) != hipSuccess) return e;
+    return attn_init_t<2, 4>();
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.kv.kblk == 3 && a.kv.vd16 == 5) return launch_attn_t<3, 5>(a, s);    // ViT-H: head_dim 80 (padded 96)
+    if (a.kv.kblk == 4 && a.kv.vd16 == 8) return launch_attn_t<4, 8>(a, s);    // Llama-7B: head_dim 128
+    if (a.kv.kblk == 1 && a.kv.vd16 == 1) return launch_attn_t<1, 1>(a, s);    // test configs: head_dim 16
+    if (a.kv.kblk == 1 && a.kv.vd16 == 2) return launch_attn_t<1, 2>(a, s);    // test configs: head_dim 32
+    if (a.kv.kblk == 2 && a.kv.vd16 == 4) return launch_attn_t<2, 4>(a, s);    // test configs: head_dim 64
+    return hipErrorInvalidValue;
+}

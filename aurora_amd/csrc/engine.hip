@@ -1,0 +1,858 @@
+// libaurora_hip.so - context, workspace carving, pipelines and the extern "C" boundary (include/aurora_hip.h).
+//
+// Pipelines restate the reference's call sequence for the AuroraCap inference path with one enqueue per
+// kernel on the caller's stream:
+//   aur_vit_encode      <- AuroraEncoder.forward + AuroraCLIPEncoder loop   (aurora.py:883-904, 772-860, 713-759)
+//   aur_project_splice  <- projector + prepare_inputs_labels_for_multimodal (aurora.py:254-258, utils.py:138-295)
+//   aur_llm_prefill / aur_llm_decode <- LlamaForCausalLM.generate greedy    (inference.py:89-96)
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/aurora_hip.h"
+#include "kernels.h"
+
+struct Tensor {
+    const void* p;
+    int64_t bytes;
+};
+
+struct VitLayerW {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
+    const half_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+};
+struct LlmLayerW {
+    const float *ln1_w, *ln2_w;
+    const half_t *qkv_w, *o_w, *gateup_w, *down_w;
+};
+
+struct StageTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double ms = 0;
+    int64_t launches = 0;
+    bool open = false;
+};
+
+struct aur_ctx {
+    aur_config cfg;
+    std::string err;
+    std::unordered_map<std::string, Tensor> tensors;
+    char* ws = nullptr;
+    int64_t ws_bytes = 0;
+    char* kvpool = nullptr;
+    int64_t kv_bytes = 0;
+    bool finalized = false;
+    // derived: vision
+    int v_hd, v_hd_pad, v_kblk, v_vd16, v_qcols, v_qkv_npad, v_dpad, v_mlp_pad, v_npatch, v_t0, v_t0pad, v_kpad;
+    // derived: llm
+    int l_hd, l_kblk, l_vd16, l_qkv_npad, l_gu_npad, l_dpad, l_vocab_pad, l_max_pages, l_ctx_pad;
+    int64_t l_page_halves, l_layer_halves;
+    // weights
+    std::vector<VitLayerW> vl;
+    std::vector<LlmLayerW> ll;
+    const half_t *v_patch_w, *v_cls, *v_pos, *p_fc1_w, *p_fc2_w, *l_embed, *l_head_w;
+    const float *v_preln_w, *v_preln_b, *p_fc1_b, *p_fc2_b, *l_norm_w;
+    // workspace regions (vision)
+    half_t *w_col, *w_patch, *w_xa, *w_xb, *w_xn, *w_qf, *w_kv, *w_attn, *w_h;
+    float *w_metric, *w_mhat, *w_nmax, *w_sza, *w_szb;
+    int32_t *w_nidx, *w_unm, *w_src, *w_dst;
+    // workspace regions (llm)
+    half_t *l_xn, *l_qf, *l_attn, *l_h, *l_p1, *d_x, *d_xn, *d_q, *d_attn, *d_h;
+    float *d_logits, *d_part_o, *d_part_ml;
+    float2* l_rope;
+    int32_t *s_pos, *s_ids, *s_len, *s_fin, *s_ptab;
+    // generation state
+    int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
+    hipGraphExec_t graph = nullptr;
+    int graph_batch = 0;
+    // profiling
+    bool prof = false;
+    std::unordered_map<std::string, StageTimer> timers;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;   // event pairs around the dominant decode kernel
+    size_t kev_used = 0;
+    double kev_ms = 0;
+    int64_t kev_n = 0;
+};
+
+static std::string g_create_err;
+
+static int aur_fail(aur_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+#define CK(expr)                                                                                       \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------ schedule
+extern "C" int32_t aur_tome_r(int32_t height, int32_t width, int32_t patch, double ratio, int32_t layers) {
+    // aurora.py:895 - same operation order in doubles: W*H / patch**2 * (1 - ratio) / L, then int()
+    const double v = (double)width * (double)height / (double)(patch * patch) * (1.0 - ratio) / (double)layers;
+    return (int32_t)v;
+}
+extern "C" int32_t aur_tokens_at_layer(int32_t t0, int32_t r, int32_t layer) {
+    int t = t0;
+    for (int l = 0; l < layer; ++l) {
+        int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;      // tome.py:45
+        if (rl > 0) t -= rl;
+    }
+    return t;
+}
+extern "C" const char* aur_version(void) { return "aurora_hip 0.1 (gfx950)"; }
+extern "C" const char* aur_last_error(const aur_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------ layout
+struct Carver {
+    int64_t off = 0;
+    char* base;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T>
+    T* take(int64_t n) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off = rup64(off + n * (int64_t)sizeof(T), 256);
+        return p;
+    }
+};
+
+static void derive(aur_ctx* c) {
+    const aur_config& g = c->cfg;
+    c->v_hd = g.vit_hidden / g.vit_heads;
+    c->v_hd_pad = rup(c->v_hd, 32);
+    c->v_kblk = c->v_hd_pad / 32;
+    c->v_vd16 = c->v_hd / 16;
+    c->v_qcols = rup(g.vit_heads * c->v_hd_pad, 64);
+    c->v_qkv_npad = rup(2 * c->v_qcols + g.vit_heads * c->v_hd, 128);
+    c->v_dpad = rup(g.vit_hidden, 128);
+    c->v_mlp_pad = rup(g.vit_mlp, 128);
+    const int gw = g.vit_image / g.vit_patch;
+    c->v_npatch = gw * gw;
+    c->v_t0 = c->v_npatch + 1;
+    c->v_t0pad = rup(c->v_t0, 32);
+    c->v_kpad = rup(g.vit_channels * g.vit_patch * g.vit_patch, 64);
+    c->l_hd = g.llm_hidden / g.llm_heads;
+    c->l_kblk = c->l_hd / 32;
+    c->l_vd16 = c->l_hd / 16;
+    c->l_qkv_npad = rup(3 * g.llm_hidden, 128);
+    c->l_gu_npad = rup(2 * g.llm_mlp, 128);
+    c->l_dpad = rup(g.llm_hidden, 128);
+    c->l_vocab_pad = rup(g.llm_vocab, 128);
+    c->l_max_pages = (g.max_ctx + g.page_tokens - 1) / g.page_tokens;
+    c->l_ctx_pad = c->l_max_pages * g.page_tokens;
+    c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
+    c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch;
+    // decode attention split: ~256 tokens per split
+    c->pps = (256 + g.page_tokens - 1) / g.page_tokens;
+    c->nsplit = (c->l_max_pages + c->pps - 1) / c->pps;
+}
+
+static int64_t vit_page_halves(const aur_ctx* c, int t_pad) { return (int64_t)c->cfg.vit_heads * t_pad * (c->v_hd_pad + c->v_hd); }
+
+static int64_t carve(aur_ctx* c, char* base) {
+    const aur_config& g = c->cfg;
+    Carver k(base);
+    const int64_t F = g.max_frames, TP = c->v_t0pad, D = g.vit_hidden;
+    c->w_col = k.take<half_t>(F * c->v_npatch * c->v_kpad);
+    c->w_patch = k.take<half_t>(F * c->v_npatch * D);
+    c->w_xa = k.take<half_t>(F * TP * D);
+    c->w_xb = k.take<half_t>(F * TP * D);
+    c->w_xn = k.take<half_t>(F * TP * D);
+    c->w_qf = k.take<half_t>(F * g.vit_heads * TP * c->v_hd_pad);
+    c->w_kv = k.take<half_t>(F * vit_page_halves(c, (int)TP));
+    c->w_attn = k.take<half_t>(F * TP * D);
+    c->w_h = k.take<half_t>(F * TP * g.vit_mlp);
+    c->w_metric = k.take<float>(F * c->v_t0 * c->v_hd);
+    c->w_mhat = k.take<float>(F * c->v_t0 * c->v_hd);
+    const int64_t ta = (c->v_t0 + 1) / 2;
+    c->w_nmax = k.take<float>(F * ta);
+    c->w_nidx = k.take<int32_t>(F * ta);
+    c->w_unm = k.take<int32_t>(F * ta);
+    c->w_src = k.take<int32_t>(F * ta);
+    c->w_dst = k.take<int32_t>(F * ta);
+    c->w_sza = k.take<float>(F * TP);
+    c->w_szb = k.take<float>(F * TP);
+    // llm
+    const int64_t LP = c->l_ctx_pad, d = g.llm_hidden, B = g.max_batch;
+    c->l_xn = k.take<half_t>(LP * d);
+    c->l_qf = k.take<half_t>(LP * d);
+    c->l_attn = k.take<half_t>(LP * d);
+    c->l_h = k.take<half_t>(LP * g.llm_mlp);
+    c->l_p1 = k.take<half_t>(LP * d);
+    c->l_rope = k.take<float2>((int64_t)c->l_ctx_pad * (c->l_hd / 2));
+    c->d_x = k.take<half_t>(B * d);
+    c->d_xn = k.take<half_t>(B * d);
+    c->d_q = k.take<half_t>(B * d);
+    c->d_attn = k.take<half_t>(B * d);
+    c->d_h = k.take<half_t>(B * g.llm_mlp);
+    c->d_logits = k.take<float>(B * g.llm_vocab);
+    c->d_part_o = k.take<float>(B * g.llm_heads * c->nsplit * c->l_hd);
+    c->d_part_ml = k.take<float>(B * g.llm_heads * c->nsplit * 2);
+    c->s_pos = k.take<int32_t>(B);
+    c->s_ids = k.take<int32_t>(B * g.max_new_tokens);
+    c->s_len = k.take<int32_t>(B);
+    c->s_fin = k.take<int32_t>(B);
+    c->s_ptab = k.take<int32_t>(B * c->l_max_pages);
+    return k.off;
+}
+
+// ------------------------------------------------------------------------------------------ lifecycle
+extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
+    if (!cfg || !out) return aur_fail(nullptr, AUR_ERR_ARG, "aur_create: null argument");
+    const aur_config& g = *cfg;
+    if (g.vit_hidden % 64 || g.vit_mlp % 64 || g.vit_hidden % g.vit_heads || (g.vit_hidden / g.vit_heads) % 16)
+        return aur_fail(nullptr, AUR_ERR_ARG, "vit dims: hidden/mlp must be multiples of 64, head_dim a multiple of 16");
+    if (g.llm_hidden % 128 || g.llm_mlp % 128 || g.llm_hidden % g.llm_heads || (g.llm_hidden / g.llm_heads) % 32)
+        return aur_fail(nullptr, AUR_ERR_ARG, "llm dims: hidden/mlp must be multiples of 128, head_dim a multiple of 32");
+    if (g.max_batch < 1 || g.max_batch > 16) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, 16]");
+    if (g.page_tokens < 64 || g.page_tokens % 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be a multiple of 64");
+    if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
+    {
+        hipError_t e;
+        if ((e = gemm_init()) != hipSuccess || (e = attn_init()) != hipSuccess || (e = tome_init()) != hipSuccess ||
+            (e = skinny_init()) != hipSuccess)
+            return aur_fail(nullptr, AUR_ERR_HIP, "kernel attribute init failed (is a gfx950 GPU visible?): %s", hipGetErrorString(e));
+    }
+    aur_ctx* c = new aur_ctx();
+    c->cfg = g;
+    derive(c);
+    *out = c;
+    return AUR_OK;
+}
+
+extern "C" void aur_destroy(aur_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->graph) hipGraphExecDestroy(ctx->graph);
+    for (auto& kv : ctx->timers) {
+        if (kv.second.e0) hipEventDestroy(kv.second.e0);
+        if (kv.second.e1) hipEventDestroy(kv.second.e1);
+    }
+    for (auto& p : ctx->kev) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    delete ctx;
+}
+
+extern "C" int aur_set_tensor(aur_ctx* ctx, const char* name, const void* dev_ptr, int64_t nbytes) {
+    if (!ctx || !name || !dev_ptr) return aur_fail(ctx, AUR_ERR_ARG, "aur_set_tensor: null argument");
+    ctx->tensors[name] = Tensor{dev_ptr, nbytes};
+    ctx->finalized = false;
+    return AUR_OK;
+}
+extern "C" int64_t aur_workspace_bytes(const aur_ctx* ctx) {
+    aur_ctx tmp = *ctx;
+    return carve(&tmp, nullptr);
+}
+extern "C" int64_t aur_kv_pool_bytes(const aur_ctx* ctx) { return ctx->l_layer_halves * ctx->cfg.llm_layers * 2; }
+extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
+    if (n < aur_workspace_bytes(ctx)) return aur_fail(ctx, AUR_ERR_ARG, "workspace too small: %lld < %lld", (long long)n, (long long)aur_workspace_bytes(ctx));
+    ctx->ws = (char*)p;
+    ctx->ws_bytes = n;
+    carve(ctx, ctx->ws);
+    ctx->finalized = false;
+    return AUR_OK;
+}
+extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
+    if (n < aur_kv_pool_bytes(ctx)) return aur_fail(ctx, AUR_ERR_ARG, "kv pool too small");
+    ctx->kvpool = (char*)p;
+    ctx->kv_bytes = n;
+    return AUR_OK;
+}
+
+template <typename T>
+static bool get(aur_ctx* c, const std::string& name, const T** out, int64_t min_bytes, bool required = true) {
+    auto it = c->tensors.find(name);
+    if (it == c->tensors.end()) {
+        if (required) aur_fail(c, AUR_ERR_STATE, "missing tensor '%s'", name.c_str());
+        *out = nullptr;
+        return !required;
+    }
+    if (it->second.bytes < min_bytes) {
+        aur_fail(c, AUR_ERR_STATE, "tensor '%s' has %lld bytes, need %lld", name.c_str(), (long long)it->second.bytes, (long long)min_bytes);
+        return false;
+    }
+    *out = (const T*)it->second.p;
+    return true;
+}
+
+extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
+    if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: workspace not set");
+    const aur_config& g = ctx->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const bool have_vit = ctx->tensors.count("vit.patch.w") > 0;
+    const bool have_llm = ctx->tensors.count("llm.embed") > 0;
+    if (have_vit) {
+        const int64_t D = g.vit_hidden;
+        bool ok = get(ctx, "vit.patch.w", &ctx->v_patch_w, (int64_t)ctx->v_dpad * ctx->v_kpad * 2) &&
+                  get(ctx, "vit.cls", &ctx->v_cls, D * 2) && get(ctx, "vit.pos", &ctx->v_pos, (int64_t)ctx->v_t0 * D * 2) &&
+                  get(ctx, "vit.preln.w", &ctx->v_preln_w, D * 4) && get(ctx, "vit.preln.b", &ctx->v_preln_b, D * 4);
+        if (!ok) return AUR_ERR_STATE;
+        // hidden_states[-2] needs layers 0 .. L-2 only: the last layer's weights are optional
+        const int nl = g.vit_layers - 1;
+        ctx->vl.assign(nl > 0 ? nl : 0, VitLayerW{});
+        for (int l = 0; l < nl; ++l) {
+            const std::string p = "vit." + std::to_string(l) + ".";
+            VitLayerW& w = ctx->vl[l];
+            ok = get(ctx, p + "ln1.w", &w.ln1_w, D * 4) && get(ctx, p + "ln1.b", &w.ln1_b, D * 4) &&
+                 get(ctx, p + "ln2.w", &w.ln2_w, D * 4) && get(ctx, p + "ln2.b", &w.ln2_b, D * 4) &&
+                 get(ctx, p + "qkv.w", &w.qkv_w, (int64_t)ctx->v_qkv_npad * D * 2) && get(ctx, p + "qkv.b", &w.qkv_b, (int64_t)ctx->v_qkv_npad * 4) &&
+                 get(ctx, p + "out.w", &w.out_w, (int64_t)ctx->v_dpad * D * 2) && get(ctx, p + "out.b", &w.out_b, (int64_t)ctx->v_dpad * 4) &&
+                 get(ctx, p + "fc1.w", &w.fc1_w, (int64_t)ctx->v_mlp_pad * D * 2) && get(ctx, p + "fc1.b", &w.fc1_b, (int64_t)ctx->v_mlp_pad * 4) &&
+                 get(ctx, p + "fc2.w", &w.fc2_w, (int64_t)ctx->v_dpad * g.vit_mlp * 2) && get(ctx, p + "fc2.b", &w.fc2_b, (int64_t)ctx->v_dpad * 4);
+            if (!ok) return AUR_ERR_STATE;
+        }
+    }
+    if (have_llm) {
+        if (!ctx->kvpool) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: kv pool not set");
+        const int64_t d = g.llm_hidden;
+        bool ok = get(ctx, "llm.embed", &ctx->l_embed, (int64_t)g.llm_vocab * d * 2) && get(ctx, "llm.norm.w", &ctx->l_norm_w, d * 4) &&
+                  get(ctx, "llm.lm_head.w", &ctx->l_head_w, (int64_t)ctx->l_vocab_pad * d * 2);
+        if (!ok) return AUR_ERR_STATE;
+        ctx->ll.assign(g.llm_layers, LlmLayerW{});
+        for (int l = 0; l < g.llm_layers; ++l) {
+            const std::string p = "llm." + std::to_string(l) + ".";
+            LlmLayerW& w = ctx->ll[l];
+            ok = get(ctx, p + "ln1.w", &w.ln1_w, d * 4) && get(ctx, p + "ln2.w", &w.ln2_w, d * 4) &&
+                 get(ctx, p + "qkv.w", &w.qkv_w, (int64_t)ctx->l_qkv_npad * d * 2) && get(ctx, p + "o.w", &w.o_w, (int64_t)ctx->l_dpad * d * 2) &&
+                 get(ctx, p + "gateup.w", &w.gateup_w, (int64_t)ctx->l_gu_npad * d * 2) &&
+                 get(ctx, p + "down.w", &w.down_w, (int64_t)ctx->l_dpad * g.llm_mlp * 2);
+            if (!ok) return AUR_ERR_STATE;
+        }
+        // projector is part of the language-side prefix path
+        if (ctx->tensors.count("proj.fc1.w")) {
+            ok = get(ctx, "proj.fc1.w", &ctx->p_fc1_w, (int64_t)ctx->l_dpad * g.vit_hidden * 2) && get(ctx, "proj.fc1.b", &ctx->p_fc1_b, (int64_t)ctx->l_dpad * 4) &&
+                 get(ctx, "proj.fc2.w", &ctx->p_fc2_w, (int64_t)ctx->l_dpad * d * 2) && get(ctx, "proj.fc2.b", &ctx->p_fc2_b, (int64_t)ctx->l_dpad * 4);
+            if (!ok) return AUR_ERR_STATE;
+        } else {
+            ctx->p_fc1_w = nullptr;
+        }
+        // RoPE table (HF linear scaling: position / factor), cos/sin in fp32 like HF
+        const int half = ctx->l_hd / 2;
+        std::vector<float2> tab((size_t)ctx->l_ctx_pad * half);
+        for (int p = 0; p < ctx->l_ctx_pad; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float inv = 1.0f / powf(g.rope_theta, (float)(2 * i) / (float)ctx->l_hd);
+                const float ang = ((float)p / g.rope_factor) * inv;
+                tab[(size_t)p * half + i] = make_float2(cosf(ang), sinf(ang));
+            }
+        CK(hipMemcpyAsync(ctx->l_rope, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, s));
+        std::vector<int32_t> pt((size_t)g.max_batch * ctx->l_max_pages);
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;      // static allocation: slot b owns pages [b*max_pages, ...)
+        CK(hipMemcpyAsync(ctx->s_ptab, pt.data(), pt.size() * 4, hipMemcpyHostToDevice, s));
+        CK(hipStreamSynchronize(s));
+    }
+    if (!have_vit && !have_llm) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: no weights were provided");
+    ctx->finalized = true;
+    return AUR_OK;
+}
+
+extern "C" int aur_pack_linear(aur_ctx* ctx, const void* w, int32_t n_src, int32_t k_src, int32_t ld_src,
+                               const int32_t* row_map, int32_t npad, int32_t kpad, void* out, void* stream) {
+    if (npad % 16 || kpad % 32 || !w || !out) return aur_fail(ctx, AUR_ERR_ARG, "aur_pack_linear: npad %% 16, kpad %% 32 required");
+    CK(launch_pack_weight((const half_t*)w, n_src, k_src, ld_src, row_map, npad, kpad, (half_t*)out, (hipStream_t)stream));
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
+    if (!c->prof) return;
+    StageTimer& t = c->timers[name];
+    if (!t.e0) {
+        hipEventCreate(&t.e0);
+        hipEventCreate(&t.e1);
+    }
+    if (t.open) {      // fold the previous interval
+        hipEventSynchronize(t.e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, t.e0, t.e1);
+        t.ms += ms;
+        t.open = false;
+    }
+    hipEventRecord(t.e0, s);
+}
+static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
+    if (!c->prof) return;
+    StageTimer& t = c->timers[name];
+    hipEventRecord(t.e1, s);
+    t.open = true;
+    t.launches++;
+}
+extern "C" int aur_profile_enable(aur_ctx* ctx, int32_t on) {
+    ctx->prof = on != 0;
+    for (auto& kv : ctx->timers) {
+        kv.second.ms = 0;
+        kv.second.launches = 0;
+        kv.second.open = false;
+    }
+    ctx->kev_used = 0;
+    ctx->kev_ms = 0;
+    ctx->kev_n = 0;
+    return AUR_OK;
+}
+static void kev_fold(aur_ctx* c) {
+    for (size_t i = 0; i < c->kev_used; ++i) {
+        hipEventSynchronize(c->kev[i].second);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->kev[i].first, c->kev[i].second) == hipSuccess) {
+            c->kev_ms += ms;
+            c->kev_n++;
+        }
+    }
+    c->kev_used = 0;
+}
+extern "C" int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out, int64_t* launches_out) {
+    if (!strcmp(stage, "decode_gemm_gateup")) {
+        kev_fold(ctx);
+        if (ms_out) *ms_out = ctx->kev_ms;
+        if (launches_out) *launches_out = ctx->kev_n;
+        return AUR_OK;
+    }
+    auto it = ctx->timers.find(stage);
+    if (it == ctx->timers.end()) {
+        if (ms_out) *ms_out = 0;
+        if (launches_out) *launches_out = 0;
+        return AUR_OK;
+    }
+    StageTimer& t = it->second;
+    if (t.open) {
+        hipEventSynchronize(t.e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, t.e0, t.e1);
+        t.ms += ms;
+        t.open = false;
+    }
+    if (ms_out) *ms_out = t.ms;
+    if (launches_out) *launches_out = t.launches;
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ vision
+static KvLayout vit_kv(const aur_ctx* c, int t_pad) {
+    KvLayout L;
+    L.base = c->w_kv;
+    L.page_table = nullptr;
+    L.max_pages = 0;
+    L.page_tokens = t_pad;
+    L.heads = c->cfg.vit_heads;
+    L.kblk = c->v_kblk;
+    L.vd16 = c->v_vd16;
+    L.page_halves = vit_page_halves(c, t_pad);
+    L.v_off = (int64_t)c->cfg.vit_heads * t_pad * c->v_hd_pad;
+    return L;
+}
+
+// One encoder layer on padded state x [F][t_pad][D] (in place for r == 0; x_out otherwise).  Returns via
+// *t_out the new token count; result lives in *x_res / *size_res (one of the two ping-pong buffers).
+static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, const float* size, half_t* x_alt, float* size_alt,
+                         half_t** x_res, const float** size_res, int* t_out, hipStream_t s) {
+    const aur_config& g = ctx->cfg;
+    const VitLayerW& w = ctx->vl[l];
+    const int D = g.vit_hidden, t_pad = rup(t, 32), M = F * t_pad;
+    CK(launch_layernorm(x, D, w.ln1_w, w.ln1_b, 1e-5f, M, D, ctx->w_xn, D, s));          // aurora.py:735 (eps: :709)
+    GemmArgs q{};
+    q.A = ctx->w_xn; q.lda = D; q.W = w.qkv_w; q.bias = w.qkv_b; q.M = M; q.Npad = ctx->v_qkv_npad; q.K = D;
+    q.rows_per_seq = t_pad; q.q_cols = ctx->v_qcols; q.k_cols = ctx->v_qcols; q.hd = ctx->v_hd; q.Qf = ctx->w_qf;
+    q.kv = vit_kv(ctx, t_pad); q.rope = nullptr; q.pos0 = 0; q.seq0 = 0;
+    CK(launch_gemm(q, EPI_QKV, s));                                                        // aurora.py:634-636
+    AttnArgs at{};
+    at.Qf = ctx->w_qf; at.kv = q.kv; at.seq0 = 0; at.nseq = F; at.heads = g.vit_heads; at.rows_per_seq = t_pad; at.t = t;
+    at.causal = 0; at.scale = 1.0f / sqrtf((float)ctx->v_hd); at.O = ctx->w_attn; at.ldo = D; at.hd = ctx->v_hd;
+    CK(launch_attention(at, s));                                                           // aurora.py:647-697
+    GemmArgs o{};
+    o.A = ctx->w_attn; o.lda = D; o.W = w.out_w; o.bias = w.out_b; o.M = M; o.Npad = ctx->v_dpad; o.K = D;
+    o.C = x; o.ldc = D; o.resid = x; o.ldr = D; o.n_real = D; o.act = ACT_NONE;
+    CK(launch_gemm(o, EPI_ROW, s));                                                        // aurora.py:699, 743
+    int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;                                            // tome.py:45
+    half_t* xc = x;
+    const float* sc = size;
+    int t2 = t;
+    if (rl > 0) {
+        CK(launch_tome_metric(q.kv, F, t, ctx->v_hd, ctx->w_metric, s));                   // aurora.py:639
+        TomeArgs ta{};
+        t2 = t - rl;
+        ta.frames = F; ta.t = t; ta.t_pad = t_pad; ta.r = rl; ta.c = ctx->v_hd; ta.d = D; ta.metric = ctx->w_metric;
+        ta.x = x; ta.size = size; ta.t_out_pad = rup(t2, 32); ta.x_out = x_alt; ta.size_out = size_alt;
+        ta.node_max = ctx->w_nmax; ta.node_idx = ctx->w_nidx; ta.unm = ctx->w_unm; ta.src = ctx->w_src; ta.dst = ctx->w_dst;
+        ta.mhat = ctx->w_mhat;
+        CK(launch_tome_step(ta, s));                                                       // aurora.py:746-747
+        xc = x_alt;
+        sc = size_alt;
+    }
+    const int t2_pad = rup(t2, 32), M2 = F * t2_pad;
+    CK(launch_layernorm(xc, D, w.ln2_w, w.ln2_b, 1e-5f, M2, D, ctx->w_xn, D, s));         // aurora.py:750
+    GemmArgs f1{};
+    f1.A = ctx->w_xn; f1.lda = D; f1.W = w.fc1_w; f1.bias = w.fc1_b; f1.M = M2; f1.Npad = ctx->v_mlp_pad; f1.K = D;
+    f1.C = ctx->w_h; f1.ldc = g.vit_mlp; f1.n_real = g.vit_mlp; f1.act = g.vit_act == AUR_ACT_GELU ? ACT_GELU : ACT_QUICK_GELU;
+    CK(launch_gemm(f1, EPI_ROW, s));
+    GemmArgs f2{};
+    f2.A = ctx->w_h; f2.lda = g.vit_mlp; f2.W = w.fc2_w; f2.bias = w.fc2_b; f2.M = M2; f2.Npad = ctx->v_dpad; f2.K = g.vit_mlp;
+    f2.C = xc; f2.ldc = D; f2.resid = xc; f2.ldr = D; f2.n_real = D; f2.act = ACT_NONE;
+    CK(launch_gemm(f2, EPI_ROW, s));                                                       // aurora.py:751-752
+    *x_res = xc;
+    *size_res = sc;
+    *t_out = t2;
+    return AUR_OK;
+}
+
+extern "C" int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
+                              int32_t* n_kept_out, void* stream) {
+    if (!ctx->finalized || ctx->vl.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_vit_encode: vision weights not finalized");
+    const aur_config& g = ctx->cfg;
+    if (frames < 1 || frames > g.max_frames) return aur_fail(ctx, AUR_ERR_ARG, "frames %d outside [1, %d]", frames, g.max_frames);
+    if (r < 0) return aur_fail(ctx, AUR_ERR_ARG, "r must be >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    stage_begin(ctx, "vit", s);
+    const int D = g.vit_hidden;
+    CK(launch_im2col((const half_t*)pixels, frames, g.vit_channels, g.vit_image, g.vit_patch, ctx->v_kpad, ctx->w_col, s));
+    GemmArgs pe{};
+    pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * ctx->v_npatch;
+    pe.Npad = ctx->v_dpad; pe.K = ctx->v_kpad; pe.C = ctx->w_patch; pe.ldc = D; pe.n_real = D; pe.act = ACT_NONE;
+    CK(launch_gemm(pe, EPI_ROW, s));
+    CK(launch_vit_assemble(ctx->w_patch, ctx->v_cls, ctx->v_pos, ctx->v_preln_w, ctx->v_preln_b, g.vit_ln_eps, frames,
+                           ctx->v_npatch, D, ctx->v_t0pad, ctx->w_xa, s));
+    half_t* x = ctx->w_xa;
+    half_t* x_alt = ctx->w_xb;
+    const float* size = nullptr;          // aurora.py:811: size = None at layer 0
+    float* size_alt = ctx->w_sza;
+    int t = ctx->v_t0;
+    for (int l = 0; l < g.vit_layers - 1; ++l) {
+        half_t* xr;
+        const float* sr;
+        int t2;
+        int rc = vit_layer_run(ctx, l, frames, t, r, x, size, x_alt, size_alt, &xr, &sr, &t2, s);
+        if (rc) return rc;
+        if (xr != x) {           // merged into the alternate buffer: swap ping-pong roles
+            x_alt = x;
+            x = xr;
+            size_alt = (sr == ctx->w_sza) ? ctx->w_szb : ctx->w_sza;
+            size = sr;
+        }
+        t = t2;
+    }
+    CK(launch_strip_cls(x, frames, t, rup(t, 32), D, (half_t*)out_tokens, s));           // aurora.py:253
+    if (n_kept_out) *n_kept_out = t - 1;
+    stage_end(ctx, "vit", s);
+    return AUR_OK;
+}
+
+extern "C" int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size, int32_t frames, int32_t t,
+                             int32_t r, void* x_out, float* size_out, float* metric_out, int32_t* node_idx,
+                             int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, void* stream) {
+    if (!ctx->finalized || layer < 0 || layer >= (int)ctx->vl.size()) return aur_fail(ctx, AUR_ERR_ARG, "aur_vit_layer: bad layer / not finalized");
+    if (frames < 1 || frames > ctx->cfg.max_frames || t < 2 || t > ctx->v_t0) return aur_fail(ctx, AUR_ERR_ARG, "aur_vit_layer: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = ctx->cfg.vit_hidden, t_pad = rup(t, 32);
+    CK(launch_pad_rows((const half_t*)x, size, frames, t, t_pad, D, ctx->w_xa, size ? ctx->w_sza : nullptr, s));
+    half_t* xr;
+    const float* sr;
+    int t2;
+    int rc = vit_layer_run(ctx, layer, frames, t, r, ctx->w_xa, size ? ctx->w_sza : nullptr, ctx->w_xb, ctx->w_szb, &xr, &sr, &t2, s);
+    if (rc) return rc;
+    CK(launch_unpad_rows(xr, sr, frames, t2, rup(t2, 32), D, (half_t*)x_out, size_out, s));
+    const int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;
+    if (rl > 0) {
+        const int ta = (t + 1) / 2;
+        if (metric_out) CK(hipMemcpyAsync(metric_out, ctx->w_metric, (size_t)frames * t * ctx->v_hd * 4, hipMemcpyDeviceToDevice, s));
+        if (node_idx) CK(hipMemcpyAsync(node_idx, ctx->w_nidx, (size_t)frames * ta * 4, hipMemcpyDeviceToDevice, s));
+        if (unm_idx) CK(hipMemcpyAsync(unm_idx, ctx->w_unm, (size_t)frames * (ta - rl) * 4, hipMemcpyDeviceToDevice, s));
+        if (src_idx) CK(hipMemcpyAsync(src_idx, ctx->w_src, (size_t)frames * rl * 4, hipMemcpyDeviceToDevice, s));
+        if (dst_idx) CK(hipMemcpyAsync(dst_idx, ctx->w_dst, (size_t)frames * rl * 4, hipMemcpyDeviceToDevice, s));
+    } else if (metric_out) {
+        KvLayout kv = vit_kv(ctx, t_pad);
+        CK(launch_tome_metric(kv, frames, t, ctx->v_hd, metric_out, s));
+    }
+    return AUR_OK;
+}
+
+extern "C" int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, const float* size, int32_t frames, int32_t t,
+                             int32_t c, int32_t d, int32_t r, void* x_out, float* size_out, int32_t* node_idx,
+                             int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, void* stream) {
+    if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_tome_step: workspace not set");
+    if (frames < 1 || t < 1 || c < 1 || (d & 7)) return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;
+    if (rl <= 0) {      // tome.py:47-48 do_nothing; merge_wavg still materialises size (tome.py:212-213)
+        CK(hipMemcpyAsync(x_out, x, (size_t)frames * t * d * 2, hipMemcpyDeviceToDevice, s));
+        CK(launch_unpad_rows((const half_t*)x, size, frames, t, t, d, (half_t*)x_out, size_out, s));
+        return AUR_OK;
+    }
+    const int64_t ta = (t + 1) / 2;
+    // scratch must fit the ctx workspace regions sized for the configured ViT
+    if ((int64_t)frames * t * c > (int64_t)ctx->cfg.max_frames * ctx->v_t0 * ctx->v_hd || (int64_t)frames * ta > (int64_t)ctx->cfg.max_frames * ((ctx->v_t0 + 1) / 2) ||
+        (int64_t)frames * rup(t, 32) * d > (int64_t)ctx->cfg.max_frames * ctx->v_t0pad * ctx->cfg.vit_hidden)
+        return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: problem larger than the workspace configured at aur_create");
+    const int t_pad = rup(t, 32), t2 = t - rl, t2_pad = rup(t2, 32);
+    CK(launch_pad_rows((const half_t*)x, size, frames, t, t_pad, d, ctx->w_xa, ctx->w_sza, s));
+    TomeArgs a{};
+    a.frames = frames; a.t = t; a.t_pad = t_pad; a.r = rl; a.c = c; a.d = d; a.metric = metric; a.x = ctx->w_xa;
+    a.size = size ? ctx->w_sza : nullptr; a.t_out_pad = t2_pad; a.x_out = ctx->w_xb; a.size_out = ctx->w_szb;
+    a.node_max = ctx->w_nmax; a.node_idx = ctx->w_nidx; a.unm = ctx->w_unm; a.src = ctx->w_src; a.dst = ctx->w_dst; a.mhat = ctx->w_mhat;
+    CK(launch_tome_step(a, s));
+    CK(launch_unpad_rows(ctx->w_xb, ctx->w_szb, frames, t2, t2_pad, d, (half_t*)x_out, size_out, s));
+    if (node_idx) CK(hipMemcpyAsync(node_idx, ctx->w_nidx, (size_t)frames * ta * 4, hipMemcpyDeviceToDevice, s));
+    if (unm_idx) CK(hipMemcpyAsync(unm_idx, ctx->w_unm, (size_t)frames * (ta - rl) * 4, hipMemcpyDeviceToDevice, s));
+    if (src_idx) CK(hipMemcpyAsync(src_idx, ctx->w_src, (size_t)frames * rl * 4, hipMemcpyDeviceToDevice, s));
+    if (dst_idx) CK(hipMemcpyAsync(dst_idx, ctx->w_dst, (size_t)frames * rl * 4, hipMemcpyDeviceToDevice, s));
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ generic ops
+extern "C" int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad, int32_t n,
+                          const float* bias, int32_t act, const void* resid, void* c, void* stream) {
+    if (m < 1 || (k & 63) || (npad & 127) || n > npad || (n & 3)) return aur_fail(ctx, AUR_ERR_ARG, "aur_linear: need k %% 64 == 0, npad %% 128 == 0, n %% 4 == 0");
+    GemmArgs g{};
+    g.A = (const half_t*)a; g.lda = k; g.W = (const half_t*)w_packed; g.bias = bias; g.M = m; g.Npad = npad; g.K = k;
+    g.C = (half_t*)c; g.ldc = n; g.resid = (const half_t*)resid; g.ldr = n; g.n_real = n;
+    g.act = act == AUR_ACT_GELU ? ACT_GELU : act == AUR_ACT_QUICK_GELU ? ACT_QUICK_GELU : ACT_NONE;
+    CK(launch_gemm(g, EPI_ROW, (hipStream_t)stream));
+    return AUR_OK;
+}
+extern "C" int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
+                                 int32_t n, float* out, void* stream) {
+    if (m < 1 || m > 16 || (k & 127) || (npad & 31) || n > npad || (n & 3)) return aur_fail(ctx, AUR_ERR_ARG, "aur_linear_skinny: need m <= 16, k %% 128 == 0");
+    SkinnyArgs s{};
+    s.x = (const half_t*)a; s.ldx = k; s.W = (const half_t*)w_packed; s.B = m; s.Npad = npad; s.K = k; s.n_real = n;
+    s.mode = SK_LOGITS; s.out32 = out;
+    CK(launch_skinny(s, (hipStream_t)stream));
+    return AUR_OK;
+}
+extern "C" int aur_layernorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, const float* b, float eps,
+                             void* y, void* stream) {
+    CK(launch_layernorm((const half_t*)x, d, w, b, eps, rows, d, (half_t*)y, d, (hipStream_t)stream));
+    return AUR_OK;
+}
+extern "C" int aur_rmsnorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, float eps, void* y, void* stream) {
+    CK(launch_rmsnorm((const half_t*)x, d, w, eps, rows, d, (half_t*)y, d, (hipStream_t)stream));
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ projector + splice
+extern "C" int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, const int32_t* vis_rows, const int32_t* text_ids,
+                                  const int32_t* text_rows, int32_t ntext, int32_t seq_len, void* embeds, void* stream) {
+    if (!ctx->finalized || !ctx->p_fc1_w) return aur_fail(ctx, AUR_ERR_STATE, "aur_project_splice: projector weights not finalized");
+    const aur_config& g = ctx->cfg;
+    if (seq_len < 1 || seq_len > g.max_ctx || nvis + ntext != seq_len) return aur_fail(ctx, AUR_ERR_ARG, "aur_project_splice: seq_len %d (nvis %d + ntext %d), max_ctx %d", seq_len, nvis, ntext, g.max_ctx);
+    hipStream_t s = (hipStream_t)stream;
+    stage_begin(ctx, "project", s);
+    const int d = g.llm_hidden, lp = rup(seq_len, 32);
+    if (lp > seq_len) CK(hipMemsetAsync((half_t*)embeds + (int64_t)seq_len * d, 0, (size_t)(lp - seq_len) * d * 2, s));
+    if (nvis > 0) {
+        GemmArgs a{};
+        a.A = (const half_t*)vis; a.lda = g.vit_hidden; a.W = ctx->p_fc1_w; a.bias = ctx->p_fc1_b; a.M = nvis; a.Npad = ctx->l_dpad;
+        a.K = g.vit_hidden; a.C = ctx->l_p1; a.ldc = d; a.n_real = d; a.act = ACT_GELU;
+        CK(launch_gemm(a, EPI_ROW, s));                                   // modeling_projector.py:20-33 (erf GELU)
+        GemmArgs b{};
+        b.A = ctx->l_p1; b.lda = d; b.W = ctx->p_fc2_w; b.bias = ctx->p_fc2_b; b.M = nvis; b.Npad = ctx->l_dpad; b.K = d;
+        b.C = (half_t*)embeds; b.ldc = d; b.n_real = d; b.act = ACT_NONE; b.out_rows = vis_rows;
+        CK(launch_gemm(b, EPI_ROW, s));                                   // written straight into the spliced rows
+    }
+    CK(launch_embed_rows(ctx->l_embed, d, text_ids, text_rows, ntext, (half_t*)embeds, d, s));   // utils.py:214-216
+    stage_end(ctx, "project", s);
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ language model
+static KvLayout llm_kv(const aur_ctx* c, int layer) {
+    KvLayout L;
+    L.base = (half_t*)c->kvpool + (int64_t)layer * c->l_layer_halves;
+    L.page_table = c->s_ptab;
+    L.max_pages = c->l_max_pages;
+    L.page_tokens = c->cfg.page_tokens;
+    L.heads = c->cfg.llm_heads;
+    L.kblk = c->l_kblk;
+    L.vd16 = c->l_vd16;
+    L.page_halves = c->l_page_halves;
+    L.v_off = c->l_page_halves / 2;
+    return L;
+}
+
+extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t eos_id, void* stream) {
+    if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_begin_batch: language weights not finalized");
+    const aur_config& g = ctx->cfg;
+    if (batch < 1 || batch > g.max_batch) return aur_fail(ctx, AUR_ERR_ARG, "batch %d outside [1, %d]", batch, g.max_batch);
+    if (max_new_tokens < 1 || max_new_tokens > g.max_new_tokens) return aur_fail(ctx, AUR_ERR_ARG, "max_new_tokens %d outside [1, %d]", max_new_tokens, g.max_new_tokens);
+    hipStream_t s = (hipStream_t)stream;
+    ctx->batch = batch;
+    ctx->max_new = max_new_tokens;
+    ctx->eos = eos_id;
+    CK(hipMemsetAsync(ctx->s_len, 0, (size_t)g.max_batch * 4, s));
+    CK(hipMemsetAsync(ctx->s_fin, 0, (size_t)g.max_batch * 4, s));
+    CK(hipMemsetAsync(ctx->s_pos, 0, (size_t)g.max_batch * 4, s));
+    CK(hipMemsetAsync(ctx->s_ids, 0, (size_t)g.max_batch * g.max_new_tokens * 4, s));
+    return AUR_OK;
+}
+
+static int lm_head_and_advance(aur_ctx* ctx, const half_t* xn, int b0, int nb, int advance, int set_pos, hipStream_t s) {
+    const aur_config& g = ctx->cfg;
+    SkinnyArgs h{};
+    h.x = xn; h.ldx = g.llm_hidden; h.W = ctx->l_head_w; h.B = nb; h.Npad = ctx->l_vocab_pad; h.K = g.llm_hidden; h.n_real = g.llm_vocab;
+    h.mode = SK_LOGITS; h.out32 = ctx->d_logits + (int64_t)b0 * g.llm_vocab;
+    CK(launch_skinny(h, s));
+    CK(launch_argmax_advance(ctx->d_logits + (int64_t)b0 * g.llm_vocab, nb, g.llm_vocab, ctx->l_embed, g.llm_hidden, ctx->eos, ctx->max_new,
+                             ctx->s_ids + (int64_t)b0 * ctx->max_new, ctx->s_len + b0, ctx->s_fin + b0, ctx->s_pos + b0,
+                             ctx->d_x + (int64_t)b0 * g.llm_hidden, g.llm_hidden, advance, set_pos, s));
+    return AUR_OK;
+}
+
+extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
+    if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_prefill: language weights not finalized");
+    const aur_config& g = ctx->cfg;
+    if (slot < 0 || slot >= ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "slot %d outside the batch of %d (aur_begin_batch)", slot, ctx->batch);
+    if (seq_len < 1 || seq_len + ctx->max_new > g.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, g.max_ctx);
+    hipStream_t s = (hipStream_t)stream;
+    stage_begin(ctx, "prefill", s);
+    const int d = g.llm_hidden, M = rup(seq_len, 32);
+    half_t* x = (half_t*)embeds;
+    for (int l = 0; l < g.llm_layers; ++l) {
+        const LlmLayerW& w = ctx->ll[l];
+        CK(launch_rmsnorm(x, d, w.ln1_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+        GemmArgs q{};
+        q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
+        q.rows_per_seq = M; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
+        q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot;
+        CK(launch_gemm(q, EPI_QKV, s));
+        AttnArgs at{};
+        at.Qf = ctx->l_qf; at.kv = q.kv; at.seq0 = slot; at.nseq = 1; at.heads = g.llm_heads; at.rows_per_seq = M; at.t = seq_len;
+        at.causal = 1; at.scale = 1.0f / sqrtf((float)ctx->l_hd); at.O = ctx->l_attn; at.ldo = d; at.hd = ctx->l_hd;
+        CK(launch_attention(at, s));
+        GemmArgs o{};
+        o.A = ctx->l_attn; o.lda = d; o.W = w.o_w; o.M = M; o.Npad = ctx->l_dpad; o.K = d; o.C = x; o.ldc = d; o.resid = x; o.ldr = d;
+        o.n_real = d; o.act = ACT_NONE;
+        CK(launch_gemm(o, EPI_ROW, s));
+        CK(launch_rmsnorm(x, d, w.ln2_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+        GemmArgs gu{};
+        gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
+        gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL;
+        CK(launch_gemm(gu, EPI_ROW, s));
+        GemmArgs dn{};
+        dn.A = ctx->l_h; dn.lda = g.llm_mlp; dn.W = w.down_w; dn.M = M; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.C = x; dn.ldc = d;
+        dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE;
+        CK(launch_gemm(dn, EPI_ROW, s));
+    }
+    // logits of the last prompt position -> first generated token
+    half_t* xn1 = ctx->d_xn + (int64_t)slot * d;
+    CK(launch_rmsnorm(x + (int64_t)(seq_len - 1) * d, d, ctx->l_norm_w, g.llm_rms_eps, 1, d, xn1, d, s));
+    int rc = lm_head_and_advance(ctx, xn1, slot, 1, 0, seq_len, s);
+    if (rc) return rc;
+    stage_end(ctx, "prefill", s);
+    return AUR_OK;
+}
+
+static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
+    const aur_config& g = ctx->cfg;
+    const int d = g.llm_hidden, B = ctx->batch;
+    for (int l = 0; l < g.llm_layers; ++l) {
+        const LlmLayerW& w = ctx->ll[l];
+        CK(launch_rmsnorm(ctx->d_x, d, w.ln1_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
+        SkinnyArgs q{};
+        q.x = ctx->d_xn; q.ldx = d; q.W = w.qkv_w; q.B = B; q.Npad = ctx->l_qkv_npad; q.K = d; q.n_real = 3 * d; q.mode = SK_QKV;
+        q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l); q.rope = ctx->l_rope; q.pos = ctx->s_pos;
+        q.seq_ids = nullptr;
+        CK(launch_skinny(q, s));
+        DecAttnArgs at{};
+        at.qbuf = ctx->d_q; at.kv = q.kv; at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = B; at.heads = g.llm_heads; at.hd = ctx->l_hd;
+        at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
+        at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out = ctx->d_attn; at.ldo = d;
+        CK(launch_decode_attention(at, s));
+        SkinnyArgs o{};
+        o.x = ctx->d_attn; o.ldx = d; o.W = w.o_w; o.B = B; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d; o.mode = SK_ROW;
+        o.out = ctx->d_x; o.ldo = d; o.resid = ctx->d_x; o.ldr = d;
+        CK(launch_skinny(o, s));
+        CK(launch_rmsnorm(ctx->d_x, d, w.ln2_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
+        SkinnyArgs gu{};
+        gu.x = ctx->d_xn; gu.ldx = d; gu.W = w.gateup_w; gu.B = B; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.n_real = 2 * g.llm_mlp;
+        gu.mode = SK_SILU_MUL; gu.out = ctx->d_h; gu.ldo = g.llm_mlp;
+        if (instrument) {
+            if (ctx->kev_used == ctx->kev.size()) {
+                hipEvent_t a, b;
+                hipEventCreate(&a);
+                hipEventCreate(&b);
+                ctx->kev.push_back({a, b});
+            }
+            hipEventRecord(ctx->kev[ctx->kev_used].first, s);
+        }
+        CK(launch_skinny(gu, s));
+        if (instrument) {
+            hipEventRecord(ctx->kev[ctx->kev_used].second, s);
+            ctx->kev_used++;
+            if (ctx->kev_used >= 4096) kev_fold(ctx);
+        }
+        SkinnyArgs dn{};
+        dn.x = ctx->d_h; dn.ldx = g.llm_mlp; dn.W = w.down_w; dn.B = B; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.n_real = d;
+        dn.mode = SK_ROW; dn.out = ctx->d_x; dn.ldo = d; dn.resid = ctx->d_x; dn.ldr = d;
+        CK(launch_skinny(dn, s));
+    }
+    CK(launch_rmsnorm(ctx->d_x, d, ctx->l_norm_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
+    return lm_head_and_advance(ctx, ctx->d_xn, 0, B, 1, -1, s);
+}
+
+extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
+    if (!ctx->finalized || ctx->ll.empty() || ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_decode: call aur_begin_batch / aur_llm_prefill first");
+    hipStream_t s = (hipStream_t)stream;
+    if (steps <= 0) return AUR_OK;
+    stage_begin(ctx, "decode", s);
+    const bool use_graph = ctx->cfg.use_graph && !ctx->prof;
+    if (use_graph) {
+        if (!ctx->graph || ctx->graph_batch != ctx->batch) {
+            if (ctx->graph) {
+                hipGraphExecDestroy(ctx->graph);
+                ctx->graph = nullptr;
+            }
+            hipGraph_t gr;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_decode_step(ctx, s, false);
+            hipError_t e = hipStreamEndCapture(s, &gr);
+            if (rc) return rc;
+            if (e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            CK(hipGraphInstantiate(&ctx->graph, gr, nullptr, nullptr, 0));
+            hipGraphDestroy(gr);
+            ctx->graph_batch = ctx->batch;
+        }
+        for (int i = 0; i < steps; ++i) CK(hipGraphLaunch(ctx->graph, s));
+    } else {
+        for (int i = 0; i < steps; ++i) {
+            int rc = enqueue_decode_step(ctx, s, ctx->prof);
+            if (rc) return rc;
+        }
+    }
+    stage_end(ctx, "decode", s);
+    return AUR_OK;
+}
+
+extern "C" int aur_get_outputs(aur_ctx* ctx, int32_t* ids_host, int32_t* lens_host, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (ids_host) CK(hipMemcpyAsync(ids_host, ctx->s_ids, (size_t)ctx->batch * ctx->max_new * 4, hipMemcpyDeviceToHost, s));
+    if (lens_host) CK(hipMemcpyAsync(lens_host, ctx->s_len, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    return AUR_OK;
+}
+extern "C" int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int32_t> fin(ctx->batch), len(ctx->batch);
+    CK(hipMemcpyAsync(fin.data(), ctx->s_fin, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(len.data(), ctx->s_len, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    int n = 0;
+    for (int b = 0; b < ctx->batch; ++b) n += (!fin[b] && len[b] < ctx->max_new) ? 1 : 0;
+    *count_host = n;
+    return AUR_OK;
+}
+extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
+    if (ctx->batch < 1 || !dst_dev) return aur_fail(ctx, AUR_ERR_STATE, "aur_copy_logits: no active batch");
+    CK(hipMemcpyAsync(dst_dev, ctx->d_logits, (size_t)ctx->batch * ctx->cfg.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AUR_OK;
+}

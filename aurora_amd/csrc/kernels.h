@@ -1,0 +1,142 @@
+// Internal kernel-launcher interface (C++ side, not part of the C ABI).
+#pragma once
+#include "common.h"
+
+enum { EPI_ROW = 0, EPI_QKV = 1 };
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2, ACT_SILU_MUL = 3 };
+
+struct GemmArgs {
+    const half_t* A;        // [M, K] row-major activations
+    int lda;
+    const half_t* W;        // FRAG-packed weights [Npad/16][K/32][512]
+    const float* bias;      // [Npad] fp32 or nullptr
+    int M, Npad, K;         // Npad % 128 == 0, K % 64 == 0
+    // ---- EPI_ROW
+    half_t* C;              // row-major output
+    int ldc;
+    const half_t* resid;    // optional residual [M, ldr] (may alias C)
+    int ldr;
+    const int32_t* out_rows;   // optional output row map (m -> row of C, <0 = drop)
+    int act;
+    int n_real;             // columns actually stored (ACT_SILU_MUL stores n_real/2)
+    // ---- EPI_QKV
+    int rows_per_seq;       // rows of A per sequence / frame (multiple of 32)
+    int q_cols, k_cols;     // padded column counts of the Q and K regions (multiples of 64)
+    int hd;                 // true head dim (V region head width; rope table row = hd/2)
+    half_t* Qf;             // Q fragments [seq][head][tok16][kblk][FRAG]
+    KvLayout kv;            // K fragments / V^T fragments destination
+    const float2* rope;     // [pos][hd/2] (cos, sin) or nullptr
+    int pos0;               // position of row 0 of each sequence (multiple of 32)
+    int seq0;               // first sequence's row in the page table
+};
+
+hipError_t gemm_init();
+hipError_t attn_init();
+hipError_t tome_init();
+hipError_t skinny_init();
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t launch_pack_weight(const half_t* w, int n_src, int k_src, int ld_src, const int32_t* row_map, int npad,
+                              int kpad, half_t* out, hipStream_t s);
+
+// ---- norm.hip
+hipError_t launch_layernorm(const half_t* x, int ldx, const float* w, const float* b, float eps, int rows, int d,
+                            half_t* y, int ldy, hipStream_t s);
+hipError_t launch_rmsnorm(const half_t* x, int ldx, const float* w, float eps, int rows, int d, half_t* y, int ldy,
+                          hipStream_t s);
+
+// ---- attn.hip (prefill / ViT flash attention over fragments)
+struct AttnArgs {
+    const half_t* Qf;       // [seq][head][tok16][kblk][FRAG]
+    KvLayout kv;
+    int seq0;               // page-table row of sequence 0
+    int nseq, heads;
+    int rows_per_seq;       // padded query rows per sequence (multiple of 32)
+    int t;                  // valid keys / queries per sequence
+    int causal;
+    float scale;            // softmax scale (hd^-0.5)
+    half_t* O;              // [nseq*rows_per_seq, ldo] row-major, head h at columns h*hd
+    int ldo;
+    int hd;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- tome.hip
+struct TomeArgs {
+    int frames, t, t_pad, r, c;      // c = metric channels (head_dim); r already clamped, > 0
+    int d;                           // hidden size
+    const float* metric;             // [frames][t][c] fp32
+    const half_t* x;                 // [frames][t_pad][d]
+    const float* size;               // [frames][t_pad] (nullptr = ones)
+    int t_out_pad;                   // padded rows per frame of the output
+    half_t* x_out;                   // [frames][t_out_pad][d]
+    float* size_out;                 // [frames][t_out_pad]
+    // scratch / optional parity outputs (device): node_max [frames][ta], node_idx [frames][ta],
+    // unm [frames][ta - r], src [frames][r], dst [frames][r]
+    float* node_max;
+    int32_t* node_idx;
+    int32_t* unm;
+    int32_t* src;
+    int32_t* dst;
+    float* mhat;                     // scratch [frames][t][c] normalised metric
+};
+hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s);
+// metric[f][tok][d] = mean over heads of K (read back from PAIRED K fragments of the ViT "pages")
+hipError_t launch_tome_metric(const KvLayout& kv, int frames, int t, int hd, float* metric, hipStream_t s);
+
+// ---- vit.hip
+hipError_t launch_im2col(const half_t* pixels, int frames, int chans, int img, int patch, int kpad, half_t* out,
+                         hipStream_t s);
+hipError_t launch_vit_assemble(const half_t* patches, const half_t* cls, const half_t* pos, const float* ln_w,
+                               const float* ln_b, float eps, int frames, int npatch, int d, int t_pad, half_t* x,
+                               hipStream_t s);
+hipError_t launch_strip_cls(const half_t* x, int frames, int t, int t_pad, int d, half_t* out, hipStream_t s);
+hipError_t launch_pad_rows(const half_t* src, const float* size_src, int frames, int t, int t_pad, int d, half_t* dst,
+                           float* size_dst, hipStream_t s);
+hipError_t launch_unpad_rows(const half_t* src, const float* size_src, int frames, int t, int t_pad, int d, half_t* dst,
+                             float* size_dst, hipStream_t s);
+hipError_t launch_gather_rows(const half_t* src, int ld_src, const int32_t* rows, int nrows, int d, half_t* dst,
+                              int ld_dst, hipStream_t s);
+hipError_t launch_embed_rows(const half_t* table, int d, const int32_t* ids, const int32_t* dst_rows, int n,
+                             half_t* dst, int ld_dst, hipStream_t s);
+
+// ---- decode.hip
+struct SkinnyArgs {
+    const half_t* x;        // [B, K] row-major
+    int ldx;
+    const half_t* W;        // FRAG-packed [Npad/16][K/32][512]
+    int B, Npad, K, n_real;
+    int mode;               // SK_ROW, SK_LOGITS, SK_SILU_MUL, SK_QKV
+    half_t* out;            // SK_ROW / SK_SILU_MUL: [B, ldo]
+    int ldo;
+    const half_t* resid;    // optional [B, ldr]
+    int ldr;
+    float* out32;           // SK_LOGITS: [B, n_real] fp32
+    // SK_QKV
+    int q_cols, k_cols, hd;
+    half_t* qbuf;           // [B][heads][kblk][4][8]   (PAIRED-d pieces)
+    KvLayout kv;
+    const float2* rope;
+    const int32_t* pos;     // [B] device: position of the new token (= tokens already cached)
+    const int32_t* seq_ids; // [B] page-table rows (nullptr = identity)
+};
+enum { SK_ROW = 0, SK_LOGITS = 1, SK_SILU_MUL = 2, SK_QKV = 3 };
+hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
+
+struct DecAttnArgs {
+    const half_t* qbuf;     // [B][heads][kblk][4][8]
+    KvLayout kv;
+    const int32_t* pos;     // [B]: keys valid = pos[b] + 1 (the new token's K/V is already written)
+    const int32_t* seq_ids;
+    int B, heads, hd;
+    int nsplit, pages_per_split;
+    float scale;
+    float* part_o;          // [B][heads][nsplit][hd]
+    float* part_ml;         // [B][heads][nsplit][2]
+    half_t* out;            // [B, heads*hd]
+    int ldo;
+};
+hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);
+
+hipError_t launch_argmax_advance(const float* logits, int B, int vocab, const half_t* embed, int d, int eos_id,
+                                 int max_new, int32_t* out_ids, int32_t* out_len, int32_t* finished, int32_t* pos,
+                                 half_t* x_next, int ldx, int advance_pos, int set_pos, hipStream_t s);

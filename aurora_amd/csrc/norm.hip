@@ -1,0 +1,89 @@
+// LayerNorm / RMSNorm for gfx950: one 64-lane wave per row, 16-byte loads, row held in registers
+// (two-pass mean / variance in fp32), fp16 in / fp16 out.  HBM-bound streaming kernels.
+//
+// Reference: nn.LayerNorm(embed_dim) in AuroraCLIPEncoderLayer (aurora.py:709,711, eps 1e-5) and HF CLIP
+// pre_layrnorm; HF LlamaRMSNorm:  w * (x_fp32 * rsqrt(mean(x_fp32^2) + eps)).to(fp16).
+#include "kernels.h"
+
+#define NORM_MAXC 8   // chunks of 8 halves per lane -> d <= 4096
+
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const half_t* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float eps, int rows, int d,
+                                                   half_t* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = d >> 3;
+    const half_t* xr = x + (int64_t)row * ldx;
+    float v[NORM_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const h8 t = *(const h8*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = (float)t[j];
+                s += RMS ? v[i][j] * v[i][j] : v[i][j];
+            }
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / (float)d + eps);
+    } else {
+        mean = s / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dlt = v[i][j] - mean;
+                    q += dlt * dlt;
+                }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)d + eps);
+    }
+    half_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = c * 8 + j;
+                float t = (v[i][j] - mean) * rstd;
+                if (RMS) {
+                    // HF: weight * hidden.to(input_dtype): round the normalised value to fp16 first
+                    t = w[k] * (float)(half_t)t;
+                } else {
+                    t = t * w[k] + b[k];
+                }
+                o[j] = (half_t)t;
+            }
+            *(h8*)(yr + c * 8) = o;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const half_t* x, int ldx, const float* w, const float* b, float eps, int rows, int d,
+                            half_t* y, int ldy, hipStream_t s) {
+    if (d > NORM_MAXC * 512 || (d & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, eps, rows, d, y, ldy);
+    return hipGetLastError();
+}
+hipError_t launch_rmsnorm(const half_t* x, int ldx, const float* w, float eps, int rows, int d, half_t* y, int ldy,
+                          hipStream_t s) {
+    if (d > NORM_MAXC * 512 || (d & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, (const float*)nullptr, eps,
+                       rows, d, y, ldy);
+    return hipGetLastError();
+}

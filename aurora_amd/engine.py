@@ -1,0 +1,432 @@
+"""Host side of the MI355X AuroraCap path: owns torch-allocated device memory (weights, workspace, KV
+pool), re-lays weights into the kernels' fragment format once, and drives libaurora_hip.so through its
+C ABI.  PyTorch is used for memory / stream housekeeping only - no torch compute op is on the hot path.
+
+Weight dictionaries use the reference checkpoints' parameter names (HF CLIP vision tower, xtuner
+projector `model.0 / model.2`, HF Llama), grouped as
+    {"vit": {...,"layers":[{...}]}, "projector": {...}, "llm": {...,"layers":[{...}]}}
+exactly like `oracle/aurora_oracle.py` consumes them, so parity tests feed both sides the same tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AurConfig, check
+
+IMAGE_TOKEN_INDEX = -200     # src/xtuner/xtuner/utils/constants.py:4
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def tome_r(height: int, width: int, patch: int, token_kept_ratio: float, num_layers: int) -> int:
+    """aurora.py:895 (evaluated inside the C library in doubles, same operation order)."""
+    return int(_lib.lib().aur_tome_r(height, width, patch, float(token_kept_ratio), num_layers))
+
+
+def tokens_at_layer(t0: int, r: int, layer: int) -> int:
+    return int(_lib.lib().aur_tokens_at_layer(t0, r, layer))
+
+
+class AuroraCapEngine:
+    def __init__(self, cfg: dict, weights: dict, *, max_frames: int = 8, max_batch: int = 1, max_ctx: int = 4096,
+                 max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.AuroraHipError("AuroraCapEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                      "there is no CPU fallback")
+        self.L = _lib.lib()
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.cfg = cfg
+        v, l = cfg.get("vit"), cfg.get("llm")
+        c = AurConfig()
+        # unused sub-models get harmless valid dims so that aur_create's checks pass
+        vv = v or dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, patch_size=14,
+                       image_size=28, hidden_act="quick_gelu")
+        ll = l or dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=128, vocab_size=128,
+                       rms_norm_eps=1e-5, rope_theta=1e4)
+        c.vit_hidden, c.vit_heads, c.vit_layers = vv["hidden_size"], vv["num_attention_heads"], vv["num_hidden_layers"]
+        c.vit_mlp, c.vit_patch, c.vit_image = vv["intermediate_size"], vv["patch_size"], vv["image_size"]
+        c.vit_channels = vv.get("num_channels", 3)
+        act = vv.get("hidden_act", "quick_gelu")
+        if act not in ("quick_gelu", "gelu"):
+            raise ValueError(f"unsupported ViT hidden_act {act!r}")
+        c.vit_act = _lib.AUR_ACT_GELU if act == "gelu" else _lib.AUR_ACT_QUICK_GELU
+        c.vit_ln_eps = vv.get("layer_norm_eps", 1e-5)
+        c.llm_hidden, c.llm_heads, c.llm_layers = ll["hidden_size"], ll["num_attention_heads"], ll["num_hidden_layers"]
+        c.llm_mlp, c.llm_vocab = ll["intermediate_size"], ll["vocab_size"]
+        c.llm_rms_eps, c.rope_theta, c.rope_factor = ll["rms_norm_eps"], ll["rope_theta"], ll.get("rope_factor", 1.0)
+        c.max_frames, c.max_batch, c.max_ctx = max_frames, max_batch, max_ctx
+        c.max_new_tokens, c.page_tokens, c.use_graph = max_new_tokens, page_tokens, int(use_graph)
+        self.c = c
+        self.v, self.l = v, l
+        self.max_new_tokens = max_new_tokens
+        self.ctx = C.c_void_p()
+        rc = self.L.aur_create(C.byref(c), C.byref(self.ctx))
+        if rc != 0:
+            raise _lib.AuroraHipError(f"aur_create failed ({rc}): {self.L.aur_last_error(None).decode()}")
+        self._keep: List[torch.Tensor] = []
+        self.ws = torch.empty(self.L.aur_workspace_bytes(self.ctx), dtype=torch.uint8, device=self.dev)
+        check(self.ctx, self.L.aur_set_workspace(self.ctx, self.ws.data_ptr(), self.ws.numel()), "aur_set_workspace")
+        self.kv = None
+        if l is not None:
+            self.kv = torch.empty(self.L.aur_kv_pool_bytes(self.ctx), dtype=torch.uint8, device=self.dev)
+            check(self.ctx, self.L.aur_set_kv_pool(self.ctx, self.kv.data_ptr(), self.kv.numel()), "aur_set_kv_pool")
+        if v is not None and "vit" in weights:
+            self._load_vit(weights["vit"])
+        if l is not None and "llm" in weights:
+            self._load_llm(weights["llm"])
+            if "projector" in weights:
+                self._load_projector(weights["projector"])
+        if (v is not None and "vit" in weights) or (l is not None and "llm" in weights):
+            check(self.ctx, self.L.aur_finalize(self.ctx, self._stream()), "aur_finalize")
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ housekeeping
+    def close(self):
+        if getattr(self, "ctx", None):
+            torch.cuda.synchronize()
+            self.L.aur_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _h(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.dev, dtype=torch.float16).contiguous()
+
+    def _f(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+    def _set(self, name: str, t: torch.Tensor):
+        self._keep.append(t)
+        check(self.ctx, self.L.aur_set_tensor(self.ctx, name.encode(), t.data_ptr(), t.numel() * t.element_size()), name)
+
+    def pack(self, w: torch.Tensor, npad: int, kpad: int, row_map: Optional[np.ndarray] = None) -> torch.Tensor:
+        """row-major [N, K] -> MFMA fragment tiles (aur_pack_linear)."""
+        w = self._h(w)
+        n, k = w.shape
+        out = torch.empty(npad * kpad, dtype=torch.float16, device=self.dev)
+        rm = None
+        if row_map is not None:
+            assert row_map.shape[0] == npad
+            rm = torch.from_numpy(row_map.astype(np.int32)).to(self.dev)
+        check(self.ctx, self.L.aur_pack_linear(self.ctx, w.data_ptr(), n, k, k, rm.data_ptr() if rm is not None else None,
+                                               npad, kpad, out.data_ptr(), self._stream()), "aur_pack_linear")
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def _bias(self, b: Optional[torch.Tensor], npad: int, row_map: Optional[np.ndarray] = None) -> torch.Tensor:
+        out = torch.zeros(npad, dtype=torch.float32, device=self.dev)
+        if b is None:
+            return out
+        b = self._f(b)
+        if row_map is None:
+            out[: b.numel()] = b
+        else:
+            rm = torch.from_numpy(row_map.astype(np.int64)).to(self.dev)
+            ok = rm >= 0
+            out[ok] = b[rm[ok]]
+        return out
+
+    # ------------------------------------------------------------------ weight loading
+    def _load_vit(self, w: dict):
+        v = self.v
+        D, H, mlp = v["hidden_size"], v["num_attention_heads"], v["intermediate_size"]
+        hd = D // H
+        hdp = _rup(hd, 32)
+        qcols = _rup(H * hdp, 64)
+        npad = _rup(2 * qcols + D, 128)
+        dpad, mpad = _rup(D, 128), _rup(mlp, 128)
+        P, Cn = v["patch_size"], v.get("num_channels", 3)
+        kpad = _rup(Cn * P * P, 64)
+        # fused QKV row map: Q and K heads padded hd -> hd_pad (zero rows), V natural
+        rm = np.full(npad, -1, np.int32)
+        for h in range(H):
+            rm[h * hdp: h * hdp + hd] = np.arange(h * hd, (h + 1) * hd)
+            rm[qcols + h * hdp: qcols + h * hdp + hd] = D + np.arange(h * hd, (h + 1) * hd)
+        rm[2 * qcols: 2 * qcols + D] = 2 * D + np.arange(D)
+        self._set("vit.patch.w", self.pack(w["patch_embedding.weight"].reshape(D, -1), dpad, kpad))
+        self._set("vit.cls", self._h(w["class_embedding"].reshape(-1)))
+        self._set("vit.pos", self._h(w["position_embedding.weight"]))
+        self._set("vit.preln.w", self._f(w["pre_layrnorm.weight"]))
+        self._set("vit.preln.b", self._f(w["pre_layrnorm.bias"]))
+        nl = v["num_hidden_layers"] - 1          # hidden_states[-2]: the last layer is never needed
+        for i in range(nl):
+            lw = w["layers"][i]
+            p = f"vit.{i}."
+            for a in ("ln1", "ln2"):
+                full = "layer_norm1" if a == "ln1" else "layer_norm2"
+                self._set(p + a + ".w", self._f(lw[full + ".weight"]))
+                self._set(p + a + ".b", self._f(lw[full + ".bias"]))
+            wqkv = torch.cat([lw["q_proj.weight"], lw["k_proj.weight"], lw["v_proj.weight"]], 0)
+            bqkv = torch.cat([lw["q_proj.bias"], lw["k_proj.bias"], lw["v_proj.bias"]], 0)
+            self._set(p + "qkv.w", self.pack(wqkv, npad, D, rm))
+            self._set(p + "qkv.b", self._bias(bqkv, npad, rm))
+            self._set(p + "out.w", self.pack(lw["out_proj.weight"], dpad, D))
+            self._set(p + "out.b", self._bias(lw["out_proj.bias"], dpad))
+            self._set(p + "fc1.w", self.pack(lw["fc1.weight"], mpad, D))
+            self._set(p + "fc1.b", self._bias(lw["fc1.bias"], mpad))
+            self._set(p + "fc2.w", self.pack(lw["fc2.weight"], dpad, mlp))
+            self._set(p + "fc2.b", self._bias(lw["fc2.bias"], dpad))
+
+    @staticmethod
+    def llama_qkv_row_map(d: int, heads: int, npad: int) -> np.ndarray:
+        """Q/K rows permuted per head so that fragment tile 2p holds d in [16p, 16p+16) and tile 2p+1 its RoPE
+        partner d + hd/2: the rotation (HF rotate_half) happens in-lane in the GEMM epilogue."""
+        hd = d // heads
+        rm = np.full(npad, -1, np.int32)
+        per_head = np.empty(hd, np.int64)
+        for p in range(hd // 32):
+            per_head[32 * p: 32 * p + 16] = 16 * p + np.arange(16)
+            per_head[32 * p + 16: 32 * p + 32] = hd // 2 + 16 * p + np.arange(16)
+        for h in range(heads):
+            rm[h * hd: (h + 1) * hd] = h * hd + per_head
+            rm[d + h * hd: d + (h + 1) * hd] = d + h * hd + per_head
+        rm[2 * d: 3 * d] = 2 * d + np.arange(d)
+        return rm
+
+    def _load_llm(self, w: dict):
+        l = self.l
+        d, H, mlp, V = l["hidden_size"], l["num_attention_heads"], l["intermediate_size"], l["vocab_size"]
+        qkv_npad, gu_npad, dpad, vpad = _rup(3 * d, 128), _rup(2 * mlp, 128), _rup(d, 128), _rup(V, 128)
+        rm_qkv = self.llama_qkv_row_map(d, H, qkv_npad)
+        rm_gu = np.full(gu_npad, -1, np.int32)
+        rm_gu[0: 2 * mlp: 2] = np.arange(mlp)
+        rm_gu[1: 2 * mlp: 2] = mlp + np.arange(mlp)
+        self._set("llm.embed", self._h(w["embed_tokens.weight"]))
+        self._set("llm.norm.w", self._f(w["norm.weight"]))
+        self._set("llm.lm_head.w", self.pack(w["lm_head.weight"], vpad, d))
+        for i, lw in enumerate(w["layers"]):
+            p = f"llm.{i}."
+            self._set(p + "ln1.w", self._f(lw["input_layernorm.weight"]))
+            self._set(p + "ln2.w", self._f(lw["post_attention_layernorm.weight"]))
+            wqkv = torch.cat([lw["q_proj.weight"], lw["k_proj.weight"], lw["v_proj.weight"]], 0)
+            self._set(p + "qkv.w", self.pack(wqkv, qkv_npad, d, rm_qkv))
+            self._set(p + "o.w", self.pack(lw["o_proj.weight"], dpad, d))
+            wgu = torch.cat([lw["gate_proj.weight"], lw["up_proj.weight"]], 0)
+            self._set(p + "gateup.w", self.pack(wgu, gu_npad, d, rm_gu))
+            self._set(p + "down.w", self.pack(lw["down_proj.weight"], dpad, mlp))
+
+    def _load_projector(self, w: dict):
+        d, dv = self.l["hidden_size"], self.v["hidden_size"]
+        dpad = _rup(d, 128)
+        self._set("proj.fc1.w", self.pack(w["model.0.weight"], dpad, dv))
+        self._set("proj.fc1.b", self._bias(w["model.0.bias"], dpad))
+        self._set("proj.fc2.w", self.pack(w["model.2.weight"], dpad, d))
+        self._set("proj.fc2.b", self._bias(w["model.2.bias"], dpad))
+
+    # ------------------------------------------------------------------ hot path
+    def tome_r(self, token_kept_ratio: float, height: Optional[int] = None, width: Optional[int] = None) -> int:
+        v = self.v
+        return tome_r(height or v["image_size"], width or v["image_size"], v["patch_size"], token_kept_ratio,
+                      v["num_hidden_layers"])
+
+    def vit_encode(self, pixels: torch.Tensor, r: int) -> torch.Tensor:
+        """pixels [F, C, H, W] -> hidden_states[-2][:, 1:]  as fp16 [F, n_kept, D]."""
+        v = self.v
+        if pixels.dim() != 4 or pixels.shape[-1] != v["image_size"] or pixels.shape[-2] != v["image_size"]:
+            raise ValueError(f"pixel_values must be [frames, C, {v['image_size']}, {v['image_size']}], got {tuple(pixels.shape)}")
+        px = self._h(pixels)
+        F = px.shape[0]
+        t0 = (v["image_size"] // v["patch_size"]) ** 2 + 1
+        n_kept = tokens_at_layer(t0, r, v["num_hidden_layers"] - 1) - 1
+        out = torch.empty(F, n_kept, v["hidden_size"], dtype=torch.float16, device=self.dev)
+        nk = C.c_int32(0)
+        check(self.ctx, self.L.aur_vit_encode(self.ctx, px.data_ptr(), F, r, out.data_ptr(), C.byref(nk), self._stream()),
+              "aur_vit_encode")
+        assert nk.value == n_kept
+        return out
+
+    def project_splice(self, vis: torch.Tensor, input_ids: Sequence[int]):
+        """vis [frames, n_kept, Dv] + ids (with -200 markers) -> (embeds [L_pad, d] fp16, seq_len).
+
+        Host builds the destination-row maps (model/utils.py:198-240 semantics: marker k takes frame k;
+        markers beyond the number of frames are dropped)."""
+        d = self.l["hidden_size"]
+        frames, n_kept = vis.shape[0], vis.shape[1]
+        vis_rows, text_ids, text_rows = [], [], []
+        row, k = 0, 0
+        for tid in input_ids:
+            if tid == IMAGE_TOKEN_INDEX:
+                if k < frames:
+                    vis_rows.append(np.arange(row, row + n_kept))
+                    row += n_kept
+                k += 1
+            else:
+                text_ids.append(int(tid))
+                text_rows.append(row)
+                row += 1
+        seq_len = row
+        used = len(vis_rows)
+        vr = np.concatenate(vis_rows) if vis_rows else np.zeros(0, np.int64)
+        vflat = self._h(vis[:used]).reshape(used * n_kept, -1)
+        vr_t = torch.from_numpy(vr.astype(np.int32)).to(self.dev)
+        ti_t = torch.tensor(text_ids, dtype=torch.int32, device=self.dev)
+        tr_t = torch.tensor(text_rows, dtype=torch.int32, device=self.dev)
+        embeds = torch.empty(_rup(seq_len, 32), d, dtype=torch.float16, device=self.dev)
+        check(self.ctx, self.L.aur_project_splice(self.ctx, vflat.data_ptr(), vflat.shape[0], vr_t.data_ptr(), ti_t.data_ptr(),
+                                                  tr_t.data_ptr(), len(text_ids), seq_len, embeds.data_ptr(), self._stream()),
+              "aur_project_splice")
+        self._tmp = (vflat, vr_t, ti_t, tr_t)      # keep alive until the stream has consumed them
+        return embeds, seq_len
+
+    def begin_batch(self, batch: int, max_new_tokens: int, eos_id: Optional[int]):
+        self._batch, self._max_new = batch, max_new_tokens
+        check(self.ctx, self.L.aur_begin_batch(self.ctx, batch, max_new_tokens, -1 if eos_id is None else int(eos_id),
+                                               self._stream()), "aur_begin_batch")
+
+    def prefill(self, slot: int, embeds: torch.Tensor, seq_len: int):
+        check(self.ctx, self.L.aur_llm_prefill(self.ctx, slot, embeds.data_ptr(), seq_len, self._stream()), "aur_llm_prefill")
+
+    def decode(self, steps: int):
+        check(self.ctx, self.L.aur_llm_decode(self.ctx, steps, self._stream()), "aur_llm_decode")
+
+    def outputs(self):
+        ids = np.zeros((self._batch, self._max_new), np.int32)
+        lens = np.zeros(self._batch, np.int32)
+        check(self.ctx, self.L.aur_get_outputs(self.ctx, ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               lens.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "aur_get_outputs")
+        return [ids[b, : lens[b]].tolist() for b in range(self._batch)]
+
+    def unfinished(self) -> int:
+        n = C.c_int32(0)
+        check(self.ctx, self.L.aur_unfinished(self.ctx, C.byref(n), self._stream()), "aur_unfinished")
+        return n.value
+
+    def logits(self) -> torch.Tensor:
+        """fp32 [batch, vocab] logits of the most recent prefill / decode step (copy)."""
+        out = torch.empty(self._batch, self.l["vocab_size"], dtype=torch.float32, device=self.dev)
+        check(self.ctx, self.L.aur_copy_logits(self.ctx, out.data_ptr(), self._stream()), "aur_copy_logits")
+        torch.cuda.synchronize()
+        return out
+
+    def generate(self, embeds_list, seq_lens, max_new_tokens: int, eos_id: Optional[int] = 2, check_every: int = 32):
+        """Greedy generation for a batch of already-spliced prefixes (one KV slot per sequence)."""
+        B = len(embeds_list)
+        self.begin_batch(B, max_new_tokens, eos_id)
+        for b in range(B):
+            self.prefill(b, embeds_list[b], seq_lens[b])
+        done = 1
+        while done < max_new_tokens:
+            n = min(check_every, max_new_tokens - done) if eos_id is not None else max_new_tokens - done
+            self.decode(n)
+            done += n
+            if eos_id is not None and self.unfinished() == 0:
+                break
+        return self.outputs()
+
+    def caption_ids(self, pixels: torch.Tensor, input_ids: Sequence[int], token_kept_ratio: float, max_new_tokens: int,
+                    eos_id: Optional[int] = 2) -> List[int]:
+        """Whole path for one clip: the call sequence of inference.py:87-96."""
+        r = self.tome_r(token_kept_ratio, pixels.shape[-2], pixels.shape[-1])
+        vis = self.vit_encode(pixels, r)
+        emb, L = self.project_splice(vis, input_ids)
+        return self.generate([emb], [L], max_new_tokens, eos_id)[0]
+
+    # ------------------------------------------------------------------ kernel-level entry points (tests)
+    def tome_step(self, metric: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], r: int):
+        F, t, c = metric.shape
+        d = x.shape[-1]
+        rl = max(0, min(r, (t - 1) // 2))
+        ta = (t + 1) // 2
+        m = self._f(metric)
+        xh = self._h(x)
+        s = self._f(size.reshape(F, t)) if size is not None else None
+        xo = torch.empty(F, t - rl, d, dtype=torch.float16, device=self.dev)
+        so = torch.empty(F, t - rl, dtype=torch.float32, device=self.dev)
+        ni = torch.zeros(F, ta, dtype=torch.int32, device=self.dev)
+        un = torch.zeros(F, max(ta - rl, 1), dtype=torch.int32, device=self.dev)
+        sr = torch.zeros(F, max(rl, 1), dtype=torch.int32, device=self.dev)
+        ds = torch.zeros(F, max(rl, 1), dtype=torch.int32, device=self.dev)
+        check(self.ctx, self.L.aur_tome_step(self.ctx, m.data_ptr(), xh.data_ptr(), s.data_ptr() if s is not None else None,
+                                             F, t, c, d, r, xo.data_ptr(), so.data_ptr(), ni.data_ptr(), un.data_ptr(),
+                                             sr.data_ptr(), ds.data_ptr(), self._stream()), "aur_tome_step")
+        torch.cuda.synchronize()
+        return xo, so, dict(r=rl, node_idx=ni, unm_idx=un[:, : ta - rl], src_idx=sr[:, :rl], dst_idx=ds[:, :rl])
+
+    def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+               resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n, k = w.shape
+        npad = _rup(n, 128)
+        wp = self.pack(w, npad, k)
+        b = self._bias(bias, npad) if bias is not None else None
+        ah = self._h(a)
+        rh = self._h(resid) if resid is not None else None
+        out = torch.empty(ah.shape[0], n, dtype=torch.float16, device=self.dev)
+        check(self.ctx, self.L.aur_linear(self.ctx, ah.data_ptr(), ah.shape[0], k, wp.data_ptr(), npad, n,
+                                          b.data_ptr() if b is not None else None, act, rh.data_ptr() if rh is not None else None,
+                                          out.data_ptr(), self._stream()), "aur_linear")
+        torch.cuda.synchronize()
+        return out
+
+    def linear_skinny(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        n, k = w.shape
+        npad = _rup(n, 128)
+        wp = self.pack(w, npad, k)
+        ah = self._h(a)
+        out = torch.empty(ah.shape[0], n, dtype=torch.float32, device=self.dev)
+        check(self.ctx, self.L.aur_linear_skinny(self.ctx, ah.data_ptr(), ah.shape[0], k, wp.data_ptr(), npad, n, out.data_ptr(),
+                                                 self._stream()), "aur_linear_skinny")
+        torch.cuda.synchronize()
+        return out
+
+    def layernorm(self, x, w, b, eps):
+        xh = self._h(x)
+        y = torch.empty_like(xh)
+        wf, bf = self._f(w), self._f(b)
+        check(self.ctx, self.L.aur_layernorm(self.ctx, xh.data_ptr(), xh.shape[0], xh.shape[1], wf.data_ptr(), bf.data_ptr(),
+                                             eps, y.data_ptr(), self._stream()), "aur_layernorm")
+        torch.cuda.synchronize()
+        return y
+
+    def rmsnorm(self, x, w, eps):
+        xh = self._h(x)
+        y = torch.empty_like(xh)
+        wf = self._f(w)
+        check(self.ctx, self.L.aur_rmsnorm(self.ctx, xh.data_ptr(), xh.shape[0], xh.shape[1], wf.data_ptr(), eps, y.data_ptr(),
+                                           self._stream()), "aur_rmsnorm")
+        torch.cuda.synchronize()
+        return y
+
+    def vit_layer(self, layer: int, x: torch.Tensor, size: Optional[torch.Tensor], r: int):
+        F, t, D = x.shape
+        hd = D // self.v["num_attention_heads"]
+        rl = max(0, min(r, (t - 1) // 2))
+        ta = (t + 1) // 2
+        xh = self._h(x)
+        s = self._f(size.reshape(F, t)) if size is not None else None
+        xo = torch.empty(F, t - rl, D, dtype=torch.float16, device=self.dev)
+        so = torch.empty(F, t - rl, dtype=torch.float32, device=self.dev)
+        me = torch.zeros(F, t, hd, dtype=torch.float32, device=self.dev)
+        ni = torch.zeros(F, ta, dtype=torch.int32, device=self.dev)
+        un = torch.zeros(F, max(ta - rl, 1), dtype=torch.int32, device=self.dev)
+        sr = torch.zeros(F, max(rl, 1), dtype=torch.int32, device=self.dev)
+        ds = torch.zeros(F, max(rl, 1), dtype=torch.int32, device=self.dev)
+        check(self.ctx, self.L.aur_vit_layer(self.ctx, layer, xh.data_ptr(), s.data_ptr() if s is not None else None, F, t, r,
+                                             xo.data_ptr(), so.data_ptr(), me.data_ptr(), ni.data_ptr(), un.data_ptr(),
+                                             sr.data_ptr(), ds.data_ptr(), self._stream()), "aur_vit_layer")
+        torch.cuda.synchronize()
+        return xo, so, me, dict(r=rl, node_idx=ni, unm_idx=un[:, : ta - rl], src_idx=sr[:, :rl], dst_idx=ds[:, :rl])
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, on: bool):
+        check(self.ctx, self.L.aur_profile_enable(self.ctx, int(on)), "aur_profile_enable")
+
+    def profile_read(self, stage: str):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self.ctx, self.L.aur_profile_read(self.ctx, stage.encode(), C.byref(ms), C.byref(n)), "aur_profile_read")
+        return ms.value, n.value

@@ -1,0 +1,157 @@
+/* aurora_hip.h - C ABI of the MI355X-native AuroraCap inference hot path (libaurora_hip.so).
+ *
+ * The reference (rese1f/aurora @ 2025-06-14) is 100 % Python and has NO FFI: this ABI is the seam a
+ * maintainer binds with ctypes to replace the eager-PyTorch calls listed per entry
+ * point.  Conventions:
+ *   - extern "C", plain C types, every call returns int status: 0 = ok, negative = error code;
+ *     no C++ exception crosses the boundary; aur_last_error(ctx) returns the message.
+ *   - The CALLER owns every buffer (weights, workspace, KV pool, inputs, outputs) and the stream.
+ *     The library owns only its ctx; hot calls never allocate device memory.
+ *   - All device pointers are raw HIP device pointers (torch: tensor.data_ptr()); `stream` is a
+ *     hipStream_t passed as void* (torch: torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it, nothing synchronises unless documented.
+ *   - One ctx per device / process; calls on one ctx are not re-entrant.
+ *   - Compute dtype: fp16 storage, fp32 accumulation (the reference runs torch.float16, inference.py:50,54).
+ */
+#ifndef AURORA_HIP_H
+#define AURORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUR_OK 0
+#define AUR_ERR_ARG -1      /* invalid argument / shape (cf. ValueError at aurora.py:649-652) */
+#define AUR_ERR_STATE -2    /* missing weight / workspace / call order */
+#define AUR_ERR_HIP -3      /* HIP runtime error */
+#define AUR_ERR_UNSUPPORTED -4 /* e.g. num_beams > 1 (cf. NotImplementedError at aurora.py:269-270) */
+
+#define AUR_ACT_QUICK_GELU 1
+#define AUR_ACT_GELU 2
+
+typedef struct aur_ctx aur_ctx;
+
+/* Model + capacity description.  Values come from the checkpoint's config.json files at load time
+ * (never hard-coded). */
+typedef struct aur_config {
+    /* vision tower: AuroraEncoder / HF CLIPVisionConfig (aurora.py:869-904) */
+    int32_t vit_hidden, vit_heads, vit_layers, vit_mlp, vit_patch, vit_image, vit_channels;
+    int32_t vit_act;            /* AUR_ACT_* from config.hidden_act */
+    float vit_ln_eps;           /* config.layer_norm_eps (pre_layrnorm); encoder layers use 1e-5 (aurora.py:709) */
+    /* projector (modeling_projector.py:20-33): vit_hidden -> llm_hidden -> llm_hidden, erf-GELU */
+    /* language model: HF LlamaConfig */
+    int32_t llm_hidden, llm_heads, llm_layers, llm_mlp, llm_vocab;
+    float llm_rms_eps, rope_theta, rope_factor;   /* linear RoPE scaling factor (vicuna-16k: 4.0) */
+    /* capacity */
+    int32_t max_frames;         /* frames per aur_vit_encode call */
+    int32_t max_batch;          /* decode slots (sequences resident in the KV pool), <= 16 */
+    int32_t max_ctx;            /* tokens per sequence (prompt + generated) */
+    int32_t max_new_tokens;     /* output buffer width per slot */
+    int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
+    int32_t use_graph;          /* 1: capture the decode step into a hipGraph */
+} aur_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int aur_create(const aur_config* cfg, aur_ctx** out);
+void aur_destroy(aur_ctx* ctx);
+const char* aur_last_error(const aur_ctx* ctx);   /* ctx may be NULL: returns the last create() error */
+const char* aur_version(void);
+
+/* Named device tensors (weights in kernel layout).  Replaces the three from_pretrained loads at
+ * inference.py:46-57.  Names: see aurora_amd/weights.py (e.g. "vit.3.qkv.w", "llm.7.down.w"). */
+int aur_set_tensor(aur_ctx* ctx, const char* name, const void* dev_ptr, int64_t nbytes);
+/* Caller-owned scratch; sizes from the two queries (depend only on cfg). */
+int64_t aur_workspace_bytes(const aur_ctx* ctx);
+int64_t aur_kv_pool_bytes(const aur_ctx* ctx);
+int aur_set_workspace(aur_ctx* ctx, void* dev_ptr, int64_t nbytes);
+int aur_set_kv_pool(aur_ctx* ctx, void* dev_ptr, int64_t nbytes);
+/* Checks that every tensor the config needs was provided; builds the RoPE table and the static page table. */
+int aur_finalize(aur_ctx* ctx, void* stream);
+
+/* Weight re-layout helper (device -> device): row-major fp16 W[n_src, k_src] (leading dim ld_src) ->
+ * MFMA fragment tiles [npad/16][kpad/32][64][8].  row_map (device int32[npad] or NULL) selects the source row
+ * of each packed row (-1 = zero row): QKV concatenation, head padding, RoPE pairing, gate/up interleave. */
+int aur_pack_linear(aur_ctx* ctx, const void* w, int32_t n_src, int32_t k_src, int32_t ld_src,
+                    const int32_t* row_map, int32_t npad, int32_t kpad, void* out, void* stream);
+
+/* ---- the token schedule (aurora.py:895, tome.py:45) -------------------------------------------- */
+/* r = int(W*H / patch^2 * (1 - ratio) / layers) evaluated in doubles in exactly that order. */
+int32_t aur_tome_r(int32_t height, int32_t width, int32_t patch, double token_kept_ratio, int32_t layers);
+/* tokens per frame entering layer `layer` (0..layers), t0 = tokens at layer 0 incl. CLS. */
+int32_t aur_tokens_at_layer(int32_t t0, int32_t r, int32_t layer);
+
+/* ---- hot path ---------------------------------------------------------------------------------- */
+/* ViT + per-layer ToMe: replaces visual_encoder(pixel_values, output_hidden_states=True)
+ * .hidden_states[-2][:, 1:]  (aurora.py:249-253; AuroraEncoder.forward aurora.py:883-904).
+ * pixels: fp16 [frames, channels, image, image] (already normalised, inference.py:71-75).
+ * out_tokens: fp16 [frames * n_kept, vit_hidden].  *n_kept_out (host) = kept tokens per frame. */
+int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
+                   int32_t* n_kept_out, void* stream);
+
+/* projector + prefix splice: replaces self.projector(...) (aurora.py:254-256) and
+ * prepare_inputs_labels_for_multimodal (model/utils.py:138-295) for one sequence.
+ * vis: fp16 [nvis, vit_hidden]; vis_rows / text_rows: device int32 destination rows in `embeds`
+ * (row order of the spliced sequence, computed on the host from input_ids); text_ids: device int32.
+ * embeds: fp16 [rows_pad, llm_hidden] with rows_pad = round_up(seq_len, 32) (pad rows zeroed here). */
+int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, const int32_t* vis_rows,
+                       const int32_t* text_ids, const int32_t* text_rows, int32_t ntext,
+                       int32_t seq_len, void* embeds, void* stream);
+
+/* Greedy generation state: replaces llm.generate(inputs_embeds=..., do_sample=False, max_new_tokens=N)
+ * (inference.py:89-96).  eos_id < 0 disables the EOS stop (benchmark: fixed-length outputs). */
+int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t eos_id, void* stream);
+/* Prefill `slot` with embeds [round_up(seq_len,32), llm_hidden] (clobbered), write its KV pages, produce the
+ * first token (argmax of the last position's logits). */
+int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream);
+/* Run `steps` decode steps for slots [0, batch): one new token per unfinished slot per step. */
+int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream);
+/* Synchronises the stream and copies results to host: ids [batch * max_new_tokens], lens [batch]. */
+int aur_get_outputs(aur_ctx* ctx, int32_t* ids_host, int32_t* lens_host, void* stream);
+/* Synchronises; number of slots still generating (EOS not seen, length < max_new_tokens). */
+int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream);
+
+/* ---- kernel-level entry points (parity tests, reuse by other callers) --------------------------- */
+/* One ToMe step on caller data: replaces bipartite_soft_matching + merge_wavg (tome.py:18-98,207-219;
+ * call site aurora.py:746-747).  metric fp32 [frames, t, c]; x fp16 [frames, t, d]; size fp32 [frames, t]
+ * or NULL (= ones); x_out fp16 [frames, t-r', d]; size_out fp32 [frames, t-r'] with r' = min(r, (t-1)/2).
+ * Optional index outputs (device int32, may be NULL): node_idx [frames, ceil(t/2)], unm_idx
+ * [frames, ceil(t/2)-r'], src_idx [frames, r'], dst_idx [frames, r'].  r' <= 0: copies x/size. */
+int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, const float* size, int32_t frames,
+                  int32_t t, int32_t c, int32_t d, int32_t r, void* x_out, float* size_out,
+                  int32_t* node_idx, int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, void* stream);
+
+/* C[M, n] = act(A[M, K] W^T + bias) (+ resid): replaces F.linear.  w_packed from aur_pack_linear
+ * (npad % 128 == 0, K % 64 == 0); bias fp32 [npad] or NULL; act 0 / AUR_ACT_*; resid fp16 [M, n] or NULL. */
+int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
+               int32_t n, const float* bias, int32_t act, const void* resid, void* c, void* stream);
+/* Same contraction through the decode (m <= 16) weight-streaming kernel; out fp32 [m, n]. */
+int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
+                      int32_t n, float* out, void* stream);
+int aur_layernorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, const float* b,
+                  float eps, void* y, void* stream);
+int aur_rmsnorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, float eps, void* y,
+                void* stream);
+
+/* One full ViT encoder layer from caller state (teacher-forced parity): replaces
+ * AuroraCLIPEncoderLayer.forward (aurora.py:713-759).  x fp16 [frames, t, D]; size fp32 [frames, t] or NULL.
+ * Outputs: x_out fp16 [frames, t', D], size_out fp32 [frames, t'], metric_out fp32 [frames, t, head_dim]
+ * (may be NULL), index arrays as in aur_tome_step (may be NULL).  Uses the ctx workspace. */
+int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size, int32_t frames, int32_t t,
+                  int32_t r, void* x_out, float* size_out, float* metric_out, int32_t* node_idx,
+                  int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, void* stream);
+
+/* Copy the last-position logits of the most recent prefill / decode step into dst_dev: fp32 [batch, vocab]. */
+int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
+
+/* Per-stage kernel-time accounting (HIP events on the caller's stream): enable, run, read back
+ * milliseconds for "vit", "project", "prefill", "decode" - and the dominant decode GEMM kernel. */
+int aur_profile_enable(aur_ctx* ctx, int32_t on);
+int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out, int64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURORA_HIP_H */

@@ -1,0 +1,179 @@
+"""GPU parity tests, kernel level, all through the C ABI (libaurora_hip.so) vs the CPU oracle.
+
+Bars: integer / index work bit-exact; floating point within the tolerance written in each test
+(fp16 storage, fp32 accumulation on the GPU vs fp32 on the CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aurora_oracle as O
+from oracle import tome_ref
+from tests.util import golden, rel_l2, tt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aurora_amd.engine import AuroraCapEngine
+    # a ViT-H-sized workspace so that path-shape ToMe problems (2 x 730 x 80, D up to 1280) fit
+    cfg = {"vit": dict(hidden_size=1280, num_attention_heads=16, num_hidden_layers=2, intermediate_size=256, patch_size=14,
+                       image_size=378, hidden_act="quick_gelu"), "llm": None}
+    e = AuroraCapEngine(cfg, {}, max_frames=2, max_batch=1, max_ctx=128, max_new_tokens=8)
+    yield e
+    e.close()
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 384, 192), (77, 256, 1280), (1000, 1280, 640), (2142, 512, 4096)])
+def test_linear_matches_fp32(eng, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = (torch.randn(m, k, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, generator=g) * 0.05).half()
+    b = (torch.randn(n, generator=g) * 0.1).half()
+    ref = a.float() @ w.float().T + b.float()
+    out = eng.linear(a, w, b).float().cpu()
+    # asymmetric operands: a transposed C-write cannot pass (guide rule 16)
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item() + 1e-3, err           # fp16 output rounding + fp32 accumulation order
+    assert rel_l2(out, ref) < 1e-3
+
+
+def test_linear_epilogues(eng):
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 200, 256, 128
+    a = (torch.randn(m, k, generator=g)).half()
+    w = (torch.randn(n, k, generator=g) * 0.1).half()
+    b = (torch.randn(n, generator=g) * 0.1).half()
+    res = torch.randn(m, n, generator=g).half()
+    z = a.float() @ w.float().T + b.float()
+    from aurora_amd._lib import AUR_ACT_GELU, AUR_ACT_QUICK_GELU
+    np.testing.assert_allclose(eng.linear(a, w, b, act=AUR_ACT_QUICK_GELU).float().cpu(), O.quick_gelu(z), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(eng.linear(a, w, b, act=AUR_ACT_GELU).float().cpu(), torch.nn.functional.gelu(z), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(eng.linear(a, w, b, resid=res).float().cpu(), z + res.float(), rtol=2e-3, atol=4e-3)
+    np.testing.assert_allclose(eng.linear(a, w, None).float().cpu(), a.float() @ w.float().T, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("b,n,k", [(1, 128, 128), (3, 256, 512), (8, 384, 4096), (16, 128, 1024), (8, 256, 11008), (5, 320, 640)])
+def test_skinny_linear_matches_fp32(eng, b, n, k):
+    g = torch.Generator().manual_seed(b * 13 + n)
+    a = (torch.randn(b, k, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, generator=g) * 0.05).half()
+    ref = a.float() @ w.float().T
+    out = eng.linear_skinny(a, w).cpu()
+    assert (out - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4      # fp32 output: accumulation order only
+
+
+def test_skinny_is_deterministic(eng):
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(8, 4096, generator=g).half()
+    w = (torch.randn(256, 4096, generator=g) * 0.05).half()
+    o1, o2 = eng.linear_skinny(a, w), eng.linear_skinny(a, w)
+    assert torch.equal(o1, o2)
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,d", [(5, 64), (730, 1280), (33, 4096), (7, 320)])
+def test_layernorm_rmsnorm(eng, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3).half()
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.1 * torch.randn(d, generator=g)
+    ref = torch.nn.functional.layer_norm(x.float(), (d,), w, b, 1e-5)
+    np.testing.assert_allclose(eng.layernorm(x, w, b, 1e-5).float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    ref2 = O.rmsnorm(x.float(), w, 1e-5)
+    np.testing.assert_allclose(eng.rmsnorm(x, w, 1e-5).float().cpu(), ref2, rtol=2e-3, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------------------------- ToMe
+def check_tome_bitexact(eng, metric, x, size, r):
+    """GPU ToMe step vs the bit-exact C oracle: indices equal, merged x / size equal bit for bit."""
+    F, t, _ = metric.shape
+    xh = x.half()
+    xo, so, idx = eng.tome_step(metric, xh, size, r)
+    mc = tome_ref.match(metric.numpy(), r)
+    if mc is None:
+        assert idx["r"] == 0
+        assert torch.equal(xo.cpu(), xh)
+        return None
+    for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(idx[k].cpu().numpy(), mc[k], err_msg=k)
+    s_np = size.reshape(F, t).numpy() if size is not None else np.ones((F, t), np.float32)
+    yc, sc = tome_ref.merge(xh.float().numpy(), s_np, mc)
+    np.testing.assert_array_equal(so.cpu().numpy(), sc)
+    np.testing.assert_array_equal(xo.cpu().numpy().view(np.uint16), torch.from_numpy(yc).half().numpy().view(np.uint16))
+    return mc
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 5])
+def test_tome_kat_g2(eng, r):
+    g = golden("g2_tome_kat.npz")
+    x8 = torch.cat([tt(g["x"]), torch.zeros(1, 9, 6)], dim=-1)                    # kernel rows are 16-byte multiples
+    xo, so, idx = eng.tome_step(tt(g["metric"]), x8, None, r)
+    for k in ("unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(idx[k].cpu().numpy(), g[f"r{r}_{k}"])
+    np.testing.assert_allclose(xo.float().cpu().numpy()[..., :2], g[f"r{r}_y"], rtol=1e-3)   # fp16 output rounding
+    np.testing.assert_array_equal(so.cpu().numpy()[..., None], g[f"r{r}_size"])
+
+
+def test_tome_tie_rule_g3(eng):
+    g = golden("g2_tome_kat.npz")
+    _, _, idx = eng.tome_step(tt(g["tie_metric"]), torch.zeros(1, 9, 8), None, 2)
+    for k in ("unm_idx", "src_idx", "dst_idx"):
+        np.testing.assert_array_equal(idx[k].cpu().numpy(), g[f"tie_{k}"])
+
+
+@pytest.mark.parametrize("t,seed", [(730, 0), (265, 1), (606, 2)])
+@pytest.mark.parametrize("r", [4, 15, 18, 22])
+def test_tome_path_shapes_vs_reference_and_oracle(eng, t, seed, r):
+    g = golden("g4_tome_shapes.npz")
+    key = f"t{t}_r{r}"
+    gen = torch.Generator().manual_seed(int(g[key + "_seed"]))
+    metric = torch.randn(2, t, 80, generator=gen)
+    x = torch.randn(2, t, 1280, generator=gen)
+    mc = check_tome_bitexact(eng, metric, x, None, r)
+    for k in ("unm_idx", "src_idx", "dst_idx"):          # and the reference's own tome.py output
+        np.testing.assert_array_equal(mc[k], g[f"{key}_{k}"])
+
+
+def test_tome_near_ties_and_exact_ties_bitexact(eng):
+    """Inputs built to contain exact and near ties: duplicated rows, fp16-quantised metrics."""
+    gen = torch.Generator().manual_seed(11)
+    metric = torch.randn(2, 301, 80, generator=gen).half().float()          # coarse grid -> near ties
+    metric[:, 10] = metric[:, 4]                                            # exact duplicates (A rows)
+    metric[:, 7] = metric[:, 3]                                             # exact duplicates (B rows)
+    metric[1, 101:140] = metric[1, 1:40]
+    x = torch.randn(2, 301, 256, generator=gen)
+    size = torch.randint(1, 6, (2, 301, 1), generator=gen).float()
+    for r in (1, 7, 150, 400):
+        check_tome_bitexact(eng, metric, x, size, r)
+
+
+@pytest.mark.parametrize("t", [2, 3, 4, 9, 31, 32, 33, 64, 65])
+def test_tome_ragged_small_sizes(eng, t):
+    gen = torch.Generator().manual_seed(100 + t)
+    metric = torch.randn(2, t, 16, generator=gen)
+    x = torch.randn(2, t, 64, generator=gen)
+    for r in (0, 1, t):
+        check_tome_bitexact(eng, metric, x, None, r)
+
+
+def test_tome_g5_sizes_vs_reference(eng):
+    g = golden("g5_merge_wavg.npz")
+    xo, so, idx = eng.tome_step(tt(g["metric"]), tt(g["x"]).float(), tt(g["size"]), 15)
+    np.testing.assert_array_equal(idx["src_idx"].cpu().numpy(), g["src_idx"])
+    np.testing.assert_array_equal(so.cpu().numpy(), g["size_out"][..., 0])
+    np.testing.assert_allclose(xo.float().cpu().numpy(), g["y"], rtol=1e-3, atol=1e-3)     # fp16 output of the fp32 reference
+
+
+def test_tome_double_run_bitwise(eng):
+    """Race screen: two runs of the same step are bitwise identical."""
+    gen = torch.Generator().manual_seed(77)
+    metric = torch.randn(2, 730, 80, generator=gen)
+    x = torch.randn(2, 730, 1280, generator=gen)
+    a = eng.tome_step(metric, x, None, 15)
+    b = eng.tome_step(metric, x, None, 15)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+        assert torch.equal(a[2][k], b[2][k])

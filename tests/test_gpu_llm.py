@@ -1,0 +1,164 @@
+"""GPU parity: projector + splice, Llama prefill and greedy decode (paged KV, hipGraph), through the C ABI,
+vs the CPU oracle.  Tolerances (SURVEY 8c iv): teacher-forced logits max-abs error relative to the logit
+scale; greedy tokens must agree wherever the oracle's top-1 / top-2 margin exceeds twice that error."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aurora_oracle as O
+from tests.util import rand_llm_weights, rand_proj_weights, rand_vit_weights, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+LLM_CFGS = {
+    "hd32": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=256, vocab_size=320,
+                 rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=4.0),
+    "hd64": dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermediate_size=384, vocab_size=500,
+                 rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=1.0),
+    "hd128": dict(hidden_size=256, num_attention_heads=2, num_hidden_layers=3, intermediate_size=640, vocab_size=1000,
+                  rms_norm_eps=1e-6, rope_theta=1e4, rope_factor=4.0),
+}
+LOGIT_TOL = 3e-2       # max-abs, relative to max |logit|
+
+
+def make_engine(cfg, seed, max_batch=2, use_graph=True, max_ctx=512, max_new=24):
+    from aurora_amd.engine import AuroraCapEngine
+    w = rand_llm_weights(cfg, seed)
+    e = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=max_batch, max_ctx=max_ctx,
+                        max_new_tokens=max_new, use_graph=use_graph)
+    return e, w
+
+
+def padded(emb):
+    L, d = emb.shape
+    lp = (L + 31) // 32 * 32
+    out = torch.zeros(lp, d, dtype=torch.float16, device="cuda")
+    out[:L] = emb.half().cuda()
+    return out
+
+
+def teacher_forced_logits(emb, ids, w, cfg):
+    """Oracle logits at every generated position given the GPU's own tokens."""
+    full = torch.cat([emb, w["embed_tokens.weight"][torch.tensor(ids[:-1], dtype=torch.long)]], 0) if len(ids) > 1 else emb
+    h, _ = O.llama_forward(full, w, cfg, None, 0)
+    return torch.nn.functional.linear(h[emb.shape[0] - 1:], w["lm_head.weight"])
+
+
+@pytest.mark.parametrize("name", list(LLM_CFGS))
+@pytest.mark.parametrize("L", [40, 97])
+def test_prefill_and_stepwise_decode_logits(name, L):
+    cfg = LLM_CFGS[name]
+    eng, w = make_engine(cfg, 5, max_batch=1, use_graph=False)
+    try:
+        gen = torch.Generator().manual_seed(L)
+        emb = torch.randn(L, cfg["hidden_size"], generator=gen).half().float()
+        nnew = 12
+        eng.begin_batch(1, nnew, None)
+        eng.prefill(0, padded(emb), L)
+        logits = [eng.logits()[0].cpu()]
+        for _ in range(nnew - 1):
+            eng.decode(1)
+            logits.append(eng.logits()[0].cpu())
+        ids = eng.outputs()[0]
+        assert len(ids) == nnew
+        ref = teacher_forced_logits(emb, ids, w, cfg)
+        scale = ref.abs().max().item()
+        for i in range(nnew):
+            err = (logits[i] - ref[i]).abs().max().item()
+            assert err <= LOGIT_TOL * scale, (i, err, scale)
+            assert int(torch.argmax(logits[i])) == ids[i]                        # greedy = first argmax of the GPU logits
+            top2 = ref[i].topk(2).values
+            if (top2[0] - top2[1]).item() > 2 * LOGIT_TOL * scale:
+                assert int(torch.argmax(ref[i])) == ids[i], i
+    finally:
+        eng.close()
+
+
+def test_greedy_matches_oracle_ids_and_graph_equals_eager():
+    cfg = LLM_CFGS["hd128"]
+    emb = torch.randn(50, cfg["hidden_size"], generator=torch.Generator().manual_seed(3)).half().float()
+    outs = []
+    for use_graph in (False, True):
+        eng, w = make_engine(cfg, 6, max_batch=1, use_graph=use_graph)
+        try:
+            outs.append(eng.generate([padded(emb)], [50], 20, eos_id=None)[0])
+        finally:
+            eng.close()
+    assert outs[0] == outs[1], "hipGraph replay must reproduce the eager decode bit for bit"
+    ref_ids, ref_logits = O.llama_greedy(emb, w, cfg, 20, eos_id=None, return_logits=True)
+    # agree up to the first position where the oracle's margin is inside the fp16 tolerance
+    scale = ref_logits.abs().max().item()
+    for i, (a, b) in enumerate(zip(outs[0], ref_ids)):
+        top2 = ref_logits[i].topk(2).values
+        if (top2[0] - top2[1]).item() <= 2 * LOGIT_TOL * scale:
+            break
+        assert a == b, i
+
+
+def test_batched_ragged_decode_equals_single():
+    """Slots with different prompt lengths decoded together give the same tokens as decoded alone."""
+    cfg = LLM_CFGS["hd64"]
+    gen = torch.Generator().manual_seed(8)
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in (33, 70, 128)]
+    eng, w = make_engine(cfg, 7, max_batch=3, use_graph=True)
+    try:
+        together = eng.generate([padded(e) for e in embs], [e.shape[0] for e in embs], 16, eos_id=None)
+        alone = [eng.generate([padded(e)], [e.shape[0]], 16, eos_id=None)[0] for e in embs]
+        assert together == alone
+    finally:
+        eng.close()
+
+
+def test_eos_stops_and_lengths():
+    cfg = LLM_CFGS["hd32"]
+    emb = torch.randn(40, cfg["hidden_size"], generator=torch.Generator().manual_seed(4)).half().float()
+    eng, w = make_engine(cfg, 9, max_batch=1, use_graph=True)
+    try:
+        free = eng.generate([padded(emb)], [40], 16, eos_id=None)[0]
+        assert len(free) == 16
+        eos = free[5]
+        first = free.index(eos)
+        stopped = eng.generate([padded(emb)], [40], 16, eos_id=eos, check_every=4)[0]
+        assert stopped == free[: first + 1]          # generation ends with the EOS token itself (HF semantics)
+    finally:
+        eng.close()
+
+
+def test_projector_splice_and_whole_path():
+    from aurora_amd.engine import AuroraCapEngine
+    vcfg = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=4, intermediate_size=128, patch_size=14,
+                image_size=56, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    lcfg = LLM_CFGS["hd32"]
+    w = {"vit": rand_vit_weights(vcfg, 1), "projector": rand_proj_weights(64, lcfg["hidden_size"], 2),
+         "llm": rand_llm_weights(lcfg, 3)}
+    eng = AuroraCapEngine({"vit": vcfg, "llm": lcfg}, w, max_frames=3, max_batch=1, max_ctx=256, max_new_tokens=16)
+    try:
+        gen = torch.Generator().manual_seed(12)
+        px = torch.randn(3, 3, 56, 56, generator=gen).half().float()
+        ids = [1, 17, -200, 18, -200, 19, -200, 20, 21, 22]
+        # projector + splice alone (teacher-forced on the GPU's ViT features)
+        r = eng.tome_r(0.5)
+        vis = eng.vit_encode(px, r)
+        emb, L = eng.project_splice(vis, ids)
+        torch.cuda.synchronize()
+        vis_ref = O.projector(vis.float().cpu().reshape(1, -1, 64), w["projector"]).reshape(3, vis.shape[1], -1)
+        emb_ref = O.splice(torch.tensor(ids), w["llm"]["embed_tokens.weight"], vis_ref)
+        assert L == emb_ref.shape[0] == 7 + 3 * vis.shape[1]
+        assert rel_l2(emb[:L].float().cpu(), emb_ref) < 5e-3
+        text_rows = [i for i, v in enumerate(emb_ref) if False]
+        np.testing.assert_array_equal(emb[0].float().cpu().numpy(), w["llm"]["embed_tokens.weight"][1].numpy())   # text rows are exact copies
+        # more markers than frames: the extra markers are dropped (utils.py:228-233)
+        emb2, L2 = eng.project_splice(vis[:2], ids)
+        assert L2 == 7 + 2 * vis.shape[1]
+        # whole path, greedy ids vs oracle (fp16-storage emulation), up to the first inside-tolerance margin
+        out = eng.caption_ids(px, ids, 0.5, 12, eos_id=None)
+        assert len(out) == 12
+        ref = O.caption_ids(px, ids, w, {"vit": vcfg, "llm": lcfg}, 0.5, 12, eos_id=None, q=O.fp16_storage)
+        agree = 0
+        for a, b in zip(out, ref):
+            if a != b:
+                break
+            agree += 1
+        assert agree >= 1
+    finally:
+        eng.close()

@@ -37,3 +37,58 @@ def enc_layers(flat, L):
 
 def cfg_of(npz, key):
     return json.loads(str(npz[key]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded synthetic weights in the oracle's (= reference checkpoint) naming
+# ---------------------------------------------------------------------------------------------------
+def rand_vit_weights(cfg, seed, wstd=0.05, bstd=0.02):
+    g = torch.Generator().manual_seed(seed)
+    D, mlp, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    P, C = cfg["patch_size"], cfg.get("num_channels", 3)
+    t0 = (cfg["image_size"] // P) ** 2 + 1
+    rn = lambda *s, std=wstd: (torch.randn(*s, generator=g) * std).half().float()
+    w = {"patch_embedding.weight": rn(D, C, P, P), "class_embedding": rn(D, std=0.5),
+         "position_embedding.weight": rn(t0, D, std=0.5),
+         "pre_layrnorm.weight": 1 + rn(D, std=0.1), "pre_layrnorm.bias": rn(D, std=bstd), "layers": []}
+    for _ in range(L):
+        lw = {}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lw[n + ".weight"], lw[n + ".bias"] = rn(D, D), rn(D, std=bstd)
+        lw["fc1.weight"], lw["fc1.bias"] = rn(mlp, D), rn(mlp, std=bstd)
+        lw["fc2.weight"], lw["fc2.bias"] = rn(D, mlp), rn(D, std=bstd)
+        for n in ("layer_norm1", "layer_norm2"):
+            lw[n + ".weight"], lw[n + ".bias"] = 1 + rn(D, std=0.1), rn(D, std=bstd)
+        w["layers"].append(lw)
+    return w
+
+
+def rand_proj_weights(dv, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std=0.05: (torch.randn(*s, generator=g) * std).half().float()
+    return {"model.0.weight": rn(d, dv), "model.0.bias": rn(d, std=0.02), "model.2.weight": rn(d, d), "model.2.bias": rn(d, std=0.02)}
+
+
+def rand_llm_weights(cfg, seed, wstd=0.05):
+    g = torch.Generator().manual_seed(seed)
+    d, mlp, V, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["num_hidden_layers"]
+    rn = lambda *s, std=wstd: (torch.randn(*s, generator=g) * std).half().float()
+    w = {"embed_tokens.weight": rn(V, d, std=1.0), "norm.weight": 1 + rn(d, std=0.1), "lm_head.weight": rn(V, d, std=0.1),
+         "layers": []}
+    for _ in range(L):
+        lw = {n + ".weight": rn(d, d) for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
+        lw["gate_proj.weight"], lw["up_proj.weight"], lw["down_proj.weight"] = rn(mlp, d), rn(mlp, d), rn(d, mlp)
+        lw["input_layernorm.weight"], lw["post_attention_layernorm.weight"] = 1 + rn(d, std=0.1), 1 + rn(d, std=0.1)
+        w["layers"].append(lw)
+    return w
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def to_match(idx: dict, device="cpu"):
+    """GPU index dict (int32 tensors) -> oracle match dict (int64, CPU)."""
+    return dict(r=idx["r"], unm_idx=idx["unm_idx"].long().to(device), src_idx=idx["src_idx"].long().to(device),
+                dst_idx=idx["dst_idx"].long().to(device))
