@@ -686,6 +686,12 @@ extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_toke
     if (batch < 1 || batch > g.max_batch) return aur_fail(ctx, AUR_ERR_ARG, "batch %d outside [1, %d]", batch, g.max_batch);
     if (max_new_tokens < 1 || max_new_tokens > g.max_new_tokens) return aur_fail(ctx, AUR_ERR_ARG, "max_new_tokens %d outside [1, %d]", max_new_tokens, g.max_new_tokens);
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->graph && (ctx->max_new != max_new_tokens || ctx->eos != eos_id || ctx->graph_batch != batch)) {
+        // eos / max_new / batch are by-value kernel arguments frozen inside the captured graph
+        CK(hipStreamSynchronize(s));
+        CK(hipGraphExecDestroy(ctx->graph));
+        ctx->graph = nullptr;
+    }
     ctx->batch = batch;
     ctx->max_new = max_new_tokens;
     ctx->eos = eos_id;

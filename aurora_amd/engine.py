@@ -44,6 +44,13 @@ class AuroraCapEngine:
         self.L = _lib.lib()
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
+        # All work is enqueued on ONE explicit (non-null) HIP stream: the null stream cannot be captured into
+        # a hipGraph.  It becomes this thread's current torch stream, so caller-side tensor housekeeping is
+        # ordered with the kernels without cross-stream events.
+        self._prev_stream = torch.cuda.current_stream(self.dev)
+        self.stream = torch.cuda.Stream(self.dev)
+        self.stream.wait_stream(self._prev_stream)
+        torch.cuda.set_stream(self.stream)
         self.cfg = cfg
         v, l = cfg.get("vit"), cfg.get("llm")
         c = AurConfig()
@@ -95,6 +102,8 @@ class AuroraCapEngine:
             torch.cuda.synchronize()
             self.L.aur_destroy(self.ctx)
             self.ctx = None
+            if torch.cuda.current_stream(self.dev) == self.stream:
+                torch.cuda.set_stream(self._prev_stream)
 
     def __del__(self):
         try:
@@ -103,7 +112,10 @@ class AuroraCapEngine:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        cur = torch.cuda.current_stream(self.dev)
+        if cur != self.stream:              # a caller switched streams: order ours after theirs
+            self.stream.wait_stream(cur)
+        return C.c_void_p(self.stream.cuda_stream)
 
     def _h(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(device=self.dev, dtype=torch.float16).contiguous()

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""AuroraCap-7B inference-path benchmark on MI355X (the metric BASELINE.json names).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
+  ViT-H/14-378 + per-layer ToMe over all frames -> projector + splice -> Llama-7B prefill per clip ->
+  batched greedy decode to exactly max_new_tokens (EOS disabled: random weights would make length arbitrary).
+Workload = BASELINE.json configs[1]: AuroraCap-7B-VID, 8 frames, token_kept_ratio 0.3, 256 new tokens, 1 GPU.
+`value` = captions/sec of the whole job (all ranks), inputs resident in HBM when the timed region starts.
+For N > 1 clips shard across ranks (one process per GPU, no data-path collective); the only collective is the
+RCCL all_gather of the generated ids at the end of each step (the reference's gather_object, evaluator.py:519-546).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
+    p.add_argument("--num_frm", type=int, default=8)
+    p.add_argument("--token_kept_ratio", type=float, default=0.3)
+    p.add_argument("--max_new_tokens", type=int, default=256)
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
+    p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, args, n_kept):
+    """Oracle (CPU port of the reference path, oracle/aurora_oracle.py) timed on the host cores on a bounded sample
+    of the same workload, extrapolated linearly to one caption."""
+    from aurora_amd import synthetic as S
+    from oracle import aurora_oracle as O
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    v, l = cfg["vit"], cfg["llm"]
+    f32 = lambda d: {k: ([f32(x) for x in val] if isinstance(val, list) else val.float().cpu()) for k, val in d.items()}
+    # --- vision sample: 1 frame through the real-depth tower (31 of 32 layers, per-layer ToMe) ---------------
+    vw = f32(S.vit_weights(v, device="cuda"))
+    px = S.frames(1, 0, v["image_size"]).float().cpu()
+    t0 = time.perf_counter()
+    feats = O.vit_features(px, vw, v, args.token_kept_ratio)
+    t_vit1 = time.perf_counter() - t0
+    assert feats.shape[1] == n_kept
+    del vw
+    # --- language sample: 2 of 32 layers at real width, prefill L0 + 4 decode tokens, lm_head per token -------
+    nl = 2
+    lw = f32(S.llm_weights(l, device="cuda", num_layers=nl))
+    L0 = 30 + args.num_frm * n_kept
+    emb = torch.randn(L0, l["hidden_size"]) * 0.02
+    sub = dict(l, num_hidden_layers=nl)
+    t0 = time.perf_counter()
+    h, kv = O.llama_forward(emb, lw, sub, None, 0)
+    t_pre = time.perf_counter() - t0
+    ndec = 4
+    t0 = time.perf_counter()
+    pos = L0
+    for _ in range(ndec):
+        logits = torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
+        nxt = int(logits.argmax())
+        h, kv = O.llama_forward(lw["embed_tokens.weight"][nxt][None], lw, sub, kv, pos)
+        pos += 1
+    t_dec = (time.perf_counter() - t0) / ndec
+    scale = l["num_hidden_layers"] / nl
+    t_lm_head = 0.0   # included in t_dec once per token (not scaled by layers): separate it
+    t0 = time.perf_counter()
+    torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
+    t_lm_head = time.perf_counter() - t0
+    per_tok = (t_dec - t_lm_head) * scale + t_lm_head
+    ttft = t_vit1 * args.num_frm + t_pre * scale
+    total = ttft + per_tok * (args.max_new_tokens - 1)
+    return dict(value=1.0 / total, unit="captions/s", cores=cores, kind="port",
+                sample=(f"oracle (PyTorch-CPU fp32 port, {cores} threads) at real dims: ViT+ToMe on 1 of {args.num_frm} frames "
+                        f"({t_vit1:.2f}s), Llama prefill of {L0} tokens + {ndec} decode tokens through {nl} of "
+                        f"{l['num_hidden_layers']} layers ({t_pre:.2f}s, {t_dec:.3f}s/token); extrapolated linearly to "
+                        f"{args.num_frm} frames, {l['num_hidden_layers']} layers, {args.max_new_tokens} tokens"),
+                ttft_s=ttft, s_per_caption=total)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine, _rup
+
+    if args.tiny:
+        cfg = {"vit": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=4, intermediate_size=256, patch_size=14,
+                           image_size=112, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+               "llm": dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermediate_size=512, vocab_size=1024,
+                           rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=4.0)}
+    else:
+        cfg = S.AURORACAP_7B
+    v, l = cfg["vit"], cfg["llm"]
+    B, F, N = args.batch, args.num_frm, args.max_new_tokens
+    dev = f"cuda:{local}"
+    weights = {"vit": S.vit_weights(v, device=dev), "projector": S.projector_weights(v["hidden_size"], l["hidden_size"], device=dev),
+               "llm": S.llm_weights(l, device=dev)}
+    t0tok = (v["image_size"] // v["patch_size"]) ** 2 + 1
+    from aurora_amd.engine import tokens_at_layer, tome_r
+    r = tome_r(v["image_size"], v["image_size"], v["patch_size"], args.token_kept_ratio, v["num_hidden_layers"])
+    n_kept = tokens_at_layer(t0tok, r, v["num_hidden_layers"] - 1) - 1
+    L0 = 30 + F * n_kept
+    max_ctx = _rup(L0 + N, 64)
+    eng = AuroraCapEngine(cfg, weights, max_frames=B * F, max_batch=B, max_ctx=max_ctx, max_new_tokens=N,
+                          use_graph=not args.no_graph, device=dev)
+    del weights
+    torch.cuda.empty_cache()
+
+    # synthetic inputs, resident in HBM before the timed region
+    clip0 = rank * B
+    pixels = torch.cat([S.frames(F, clip0 + b, v["image_size"], device=dev) for b in range(B)], 0)     # [B*F, 3, H, W]
+    ids = [S.prompt_ids(F, clip0 + b, 30, l["vocab_size"]) for b in range(B)]
+    torch.cuda.synchronize()
+
+    ttft_ms = []
+
+    def step(record_ttft=False):
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        vis = eng.vit_encode(pixels, r)                            # [B*F, n_kept, Dv]
+        eng.begin_batch(B, N, None)
+        evs = []
+        for b in range(B):
+            emb, L = eng.project_splice(vis[b * F:(b + 1) * F], ids[b])
+            eng.prefill(b, emb, L)
+            if record_ttft:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+        eng.decode(N - 1)
+        out = eng.outputs()                                        # synchronises
+        if world > 1:                                              # result gather over RCCL / xGMI
+            t = torch.tensor(out, dtype=torch.int32, device=dev)
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+        if record_ttft:
+            ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(record_ttft=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        captions = world * B * args.steps
+        value = captions / elapsed
+        result = {
+            "metric": "captions/sec (AuroraCap-7B, 8-frame clips, token_kept_ratio 0.3, 256 new tokens) + p50 TTFT",
+            "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[1])"
+                                    % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
+                       "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
+                       "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
+                       "decode": "hipGraph" if not args.no_graph else "eager"},
+            "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
+            "ttft_note": "time from step start to each clip's first token inside a batch of %d clips (ViT for all clips runs first)" % B,
+        }
+
+    # ---- instrumented pass (rank 0, after the timed region): HIP events per stage and around the dominant kernel
+    if rank == 0 and not args.no_instrument:
+        eng.profile(True)
+        step()
+        stages = {k: eng.profile_read(k)[0] for k in ("vit", "project", "prefill", "decode")}
+        kms, kn = eng.profile_read("decode_gemm_gateup")
+        eng.profile(False)
+        result["stage_ms_instrumented_step"] = stages
+        d, mlp = l["hidden_size"], l["intermediate_size"]
+        wbytes = 2 * mlp * d * 2                                   # gate+up rows, fp16
+        alg = wbytes + B * d * 2 + B * mlp * 2                     # + x in + h out
+        if kn > 0:
+            avg_s = kms / kn * 1e-3
+            result["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel<2, SK_SILU_MUL> (decode gate/up projection)",
+                                  "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
+                                  "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6,
+                                  "launches_timed": kn,
+                                  "how": "HIP events around every launch of this kernel in one extra eager step on the launch stream"}
+        # single-clip latency (batch 1): TTFT without queueing behind other clips' ViT/prefill
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lat = []
+        for _ in range(3):
+            e0.record()
+            vis = eng.vit_encode(pixels[:F], r)
+            eng.begin_batch(1, N, None)
+            emb, L = eng.project_splice(vis, ids[0])
+            eng.prefill(0, emb, L)
+            e1.record()
+            torch.cuda.synchronize()
+            lat.append(e0.elapsed_time(e1))
+        result["ttft_ms_single_clip"] = float(np.median(lat))
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
+        try:
+            result["cpu_baseline"] = cpu_baseline(cfg, args, n_kept)
+        except Exception as ex:                                    # the bench line must still print
+            result["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
