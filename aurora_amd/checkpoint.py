@@ -1,0 +1,111 @@
+"""Checkpoint loading for the xtuner-format AuroraCap directory (host-side housekeeping).
+
+Layout written by the reference (aurora.py:312-362 `to_xtuner_llava`, consumed at inference.py:42-57):
+    <root>/                 HF Llama (config.json + *.safetensors | pytorch_model*.bin) + tokenizer files
+    <root>/visual_encoder/  HF CLIP vision tower  (keys vision_model.*; `visual_encoder.pos_emb` aliases
+                            position_embedding.weight, aurora.py:878 / pth_to_hf.py:119-124)
+    <root>/projector/       xtuner ProjectorModel (keys model.0.*, model.2.*)
+Everything architectural is read from the config.json files - never hard-coded.
+Returns (cfg, weights) in the naming of aurora_amd.engine / oracle.aurora_oracle.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from typing import Dict, Tuple
+
+import torch
+
+
+def _load_state(d: str) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    st = sorted(glob.glob(os.path.join(d, "*.safetensors")))
+    if st:
+        from safetensors.torch import load_file
+        for f in st:
+            sd.update(load_file(f))
+        return sd
+    bins = sorted(glob.glob(os.path.join(d, "pytorch_model*.bin")))
+    if not bins:
+        raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {d}")
+    for f in bins:
+        sd.update(torch.load(f, map_location="cpu", weights_only=True))
+    return sd
+
+
+def _json(p):
+    with open(p) as f:
+        return json.load(f)
+
+
+def vit_config(d: str) -> dict:
+    c = _json(os.path.join(d, "config.json"))
+    c = c.get("vision_config", c)
+    return dict(hidden_size=c["hidden_size"], num_attention_heads=c["num_attention_heads"],
+                num_hidden_layers=c["num_hidden_layers"], intermediate_size=c["intermediate_size"],
+                patch_size=c["patch_size"], image_size=c["image_size"], num_channels=c.get("num_channels", 3),
+                hidden_act=c.get("hidden_act", "quick_gelu"), layer_norm_eps=c.get("layer_norm_eps", 1e-5))
+
+
+def llm_config(d: str) -> dict:
+    c = _json(os.path.join(d, "config.json"))
+    if c.get("num_key_value_heads", c["num_attention_heads"]) != c["num_attention_heads"]:
+        raise NotImplementedError("grouped-query attention is not on the AuroraCap-7B path (vicuna-7b is MHA)")
+    rs = c.get("rope_scaling") or {}
+    kind = rs.get("type", rs.get("rope_type", "linear" if rs else None))
+    if rs and kind not in ("linear", "default", None):
+        raise NotImplementedError(f"rope_scaling type {kind!r} (vicuna-7b-v1.5-16k uses linear)")
+    return dict(hidden_size=c["hidden_size"], num_attention_heads=c["num_attention_heads"],
+                num_hidden_layers=c["num_hidden_layers"], intermediate_size=c["intermediate_size"],
+                vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-5), rope_theta=c.get("rope_theta", 10000.0),
+                rope_factor=float(rs.get("factor", 1.0)) if kind == "linear" else 1.0,
+                eos_token_id=c.get("eos_token_id", 2), bos_token_id=c.get("bos_token_id", 1))
+
+
+def vit_weights(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
+    p = "vision_model."
+    if not any(k.startswith(p) for k in sd):
+        p = ""
+    g = lambda k: sd[p + k]
+    w = {"patch_embedding.weight": g("embeddings.patch_embedding.weight"), "class_embedding": g("embeddings.class_embedding"),
+         "position_embedding.weight": sd.get("pos_emb", g("embeddings.position_embedding.weight")),
+         "pre_layrnorm.weight": g("pre_layrnorm.weight"), "pre_layrnorm.bias": g("pre_layrnorm.bias"), "layers": []}
+    for i in range(cfg["num_hidden_layers"]):
+        q = f"encoder.layers.{i}."
+        lw = {}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lw[n + ".weight"], lw[n + ".bias"] = g(q + f"self_attn.{n}.weight"), g(q + f"self_attn.{n}.bias")
+        for n in ("fc1", "fc2"):
+            lw[n + ".weight"], lw[n + ".bias"] = g(q + f"mlp.{n}.weight"), g(q + f"mlp.{n}.bias")
+        for n in ("layer_norm1", "layer_norm2"):
+            lw[n + ".weight"], lw[n + ".bias"] = g(q + n + ".weight"), g(q + n + ".bias")
+        w["layers"].append(lw)
+    return w
+
+
+def llm_weights(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
+    w = {"embed_tokens.weight": sd["model.embed_tokens.weight"], "norm.weight": sd["model.norm.weight"],
+         "lm_head.weight": sd.get("lm_head.weight", sd["model.embed_tokens.weight"]), "layers": []}
+    for i in range(cfg["num_hidden_layers"]):
+        q = f"model.layers.{i}."
+        lw = {n + ".weight": sd[q + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
+        for n in ("gate_proj", "up_proj", "down_proj"):
+            lw[n + ".weight"] = sd[q + f"mlp.{n}.weight"]
+        lw["input_layernorm.weight"] = sd[q + "input_layernorm.weight"]
+        lw["post_attention_layernorm.weight"] = sd[q + "post_attention_layernorm.weight"]
+        w["layers"].append(lw)
+    return w
+
+
+def load_auroracap(root: str) -> Tuple[dict, dict]:
+    """(cfg, weights) from an xtuner-format AuroraCap directory."""
+    vdir, pdir = os.path.join(root, "visual_encoder"), os.path.join(root, "projector")
+    for d in (root, vdir, pdir):
+        if not os.path.isdir(d):
+            raise FileNotFoundError(f"{d} is not a directory (expected <root>/, <root>/visual_encoder, <root>/projector)")
+    cfg = {"vit": vit_config(vdir), "llm": llm_config(root)}
+    psd = _load_state(pdir)
+    weights = {"vit": vit_weights(_load_state(vdir), cfg["vit"]), "llm": llm_weights(_load_state(root), cfg["llm"]),
+               "projector": {k: psd[k] for k in ("model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias")}}
+    return cfg, weights

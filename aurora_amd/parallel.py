@@ -1,0 +1,55 @@
+"""Clip-parallel sharding and result gather (one process per GPU, RCCL over xGMI; gloo on CPU in tests).
+
+The path shards by independent clips; there is NO data-path collective.  Mirrors what the reference's
+evaluation harness does: round-robin `islice(docs, rank, None, world_size)`
+(src/lmms-eval/lmms_eval/utils.py:675-681) and `gather_object` of the results
+(src/lmms-eval/lmms_eval/evaluator.py:519-546) - here one fixed-shape int32 all_gather per batch
+(<= clips_per_rank x max_new_tokens ids + lengths: latency-bound, a few KiB).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def shard_clips(n_clips: int, rank: int, world: int) -> List[int]:
+    """Clip indices owned by `rank`: i with i % world == rank (round-robin, like lmms-eval)."""
+    return list(range(rank, n_clips, world))
+
+
+def gather_results(local_ids: Sequence[Sequence[int]], max_new_tokens: int, clips_per_rank: int, device, group=None):
+    """All-gather variable-length id lists.  Returns {rank: [ids...]} on every rank.
+
+    Wire format: int32 [clips_per_rank, 1 + max_new_tokens] per rank (col 0 = length, -1 = no clip)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    buf = torch.full((clips_per_rank, 1 + max_new_tokens), -1, dtype=torch.int32)
+    for i, ids in enumerate(local_ids):
+        n = min(len(ids), max_new_tokens)
+        buf[i, 0] = n
+        if n:
+            buf[i, 1:1 + n] = torch.tensor(list(ids)[:n], dtype=torch.int32)
+    buf = buf.to(device)
+    if world == 1:
+        bufs = [buf]
+    else:
+        bufs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf, group=group)
+    out = {}
+    for rk, b in enumerate(bufs):
+        b = b.cpu()
+        out[rk] = [b[i, 1:1 + int(b[i, 0])].tolist() for i in range(clips_per_rank) if int(b[i, 0]) >= 0]
+    return out
+
+
+def merge_round_robin(per_rank: dict, n_clips: int) -> List[Optional[List[int]]]:
+    """Undo shard_clips: results in original clip order."""
+    world = len(per_rank)
+    out: List[Optional[List[int]]] = [None] * n_clips
+    for rk, res in per_rank.items():
+        for j, ids in enumerate(res):
+            idx = rk + j * world
+            if idx < n_clips:
+                out[idx] = ids
+    return out

@@ -151,9 +151,8 @@ def main():
         eng.decode(N - 1)
         out = eng.outputs()                                        # synchronises
         if world > 1:                                              # result gather over RCCL / xGMI
-            t = torch.tensor(out, dtype=torch.int32, device=dev)
-            gathered = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(gathered, t)
+            from aurora_amd import parallel
+            parallel.gather_results(out, N, B, dev)
         if record_ttft:
             ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
         return out

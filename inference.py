@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""AuroraCap inference on MI355X - same argument surface and stdout contract as the reference CLI
+(rese1f/aurora inference.py:29-98): prints one caption string.
+
+    python inference.py --model_path <xtuner-format dir> --visual_input clip.mp4 --num_frm 8 \
+        --token_kept_ratio 0.3 --max_new_tokens 256
+
+Host-side preprocessing (tokenizer, CLIP image processor, PyAV frame sampling) uses the same third-party
+packages the reference uses; the three hot stages run in libaurora_hip.so.
+`--synthetic` replaces checkpoint, tokenizer and video by the seeded synthetic clip of SURVEY 8d (prints ids).
+"""
+import argparse
+import os.path as osp
+import sys
+
+import numpy as np
+import torch
+
+
+def read_video_pyav(path: str, num_frm: int = 8):
+    """Uniform frame sampling, src/xtuner/xtuner/tools/load_video.py:31-71 semantics:
+    indices = linspace(0, total-1, num_frm, dtype=int); the last frame is appended when missing."""
+    try:
+        import av
+    except ImportError as e:
+        raise RuntimeError("PyAV (`av`) is required to decode video input") from e
+    container = av.open(path)
+    total = container.streams.video[0].frames
+    if total <= 0:                                   # webm / mkv: count by decoding packets (load_video.py fallback)
+        frames = [f for f in container.decode(video=0)]
+        total = len(frames)
+        idx = np.linspace(0, total - 1, num_frm, dtype=int).tolist()
+        if total - 1 not in idx:
+            idx.append(total - 1)
+        return np.stack([frames[i].to_ndarray(format="rgb24") for i in idx])
+    idx = set(np.linspace(0, total - 1, num_frm, dtype=int).tolist())
+    idx.add(total - 1)
+    out = []
+    container.seek(0)
+    for i, frame in enumerate(container.decode(video=0)):
+        if i in idx:
+            out.append(frame.to_ndarray(format="rgb24"))
+        if i > max(idx):
+            break
+    return np.stack(out)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--model_path', type=str, help='path to the model', default='wchai/AuroraCap-7B-IMG-xtuner')
+    parser.add_argument('--prompt', type=str, help='prompt for the model', default='Describe the video in detail.')
+    parser.add_argument('--visual_input', type=str, help='path to the video or image file', default='output.png')
+    parser.add_argument('--num_frm', type=int, help='number of frames to sample from the video', default=8)
+    parser.add_argument('--token_kept_ratio', type=float, help='token merge ratio', default=0.8)
+    parser.add_argument('--temperature', type=float, help='temperature', default=0.0)
+    parser.add_argument('--top_p', type=float, help='top p', default=1.0)
+    parser.add_argument('--num_beams', type=int, help='number of beams', default=1)
+    parser.add_argument('--max_new_tokens', type=int, help='max new tokens', default=2048)
+    parser.add_argument('--synthetic', action='store_true', help='seeded synthetic weights / clip / prompt ids (no checkpoint needed)')
+    args = parser.parse_args()
+    if args.num_beams != 1:
+        sys.exit("error: only greedy decoding is implemented on the MI355X path (--num_beams 1)")
+
+    from aurora_amd.model import AuroraModel, build_prompt, process_text
+
+    if args.synthetic:
+        from aurora_amd import synthetic as S
+        from aurora_amd.engine import AuroraCapEngine
+        cfg = S.AURORACAP_7B
+        w = {"vit": S.vit_weights(cfg["vit"]), "projector": S.projector_weights(1280, 4096), "llm": S.llm_weights(cfg["llm"])}
+        eng = AuroraCapEngine(cfg, w, max_frames=args.num_frm, max_batch=1, max_ctx=30 + args.num_frm * 729 + args.max_new_tokens + 64,
+                              max_new_tokens=args.max_new_tokens)
+        model = AuroraModel(eng, eos_token_id=None)
+        data = {"pixel_values": S.frames(args.num_frm, 0).unsqueeze(0), "input_ids": torch.tensor([S.prompt_ids(args.num_frm, 0)])}
+        tokenizer = None
+    else:
+        from transformers import AutoTokenizer, CLIPImageProcessor
+        if not osp.isdir(args.model_path):
+            from huggingface_hub import snapshot_download
+            args.model_path = snapshot_download(repo_id=args.model_path)
+        max_ctx = 128 + args.num_frm * 729 + args.max_new_tokens
+        model = AuroraModel.from_pretrained(args.model_path, max_frames=max(args.num_frm + 1, 2), max_ctx=max_ctx,
+                                            max_new_tokens=args.max_new_tokens)
+        image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=378, crop_size=378)
+        tokenizer = AutoTokenizer.from_pretrained(args.model_path, trust_remote_code=True, padding_side='right')
+        data = dict()
+        if args.visual_input.endswith('mp4'):
+            video_frames = read_video_pyav(args.visual_input, args.num_frm)
+            image_tensor = image_processor(list(video_frames), return_tensors='pt')['pixel_values']
+            data["pixel_values"] = image_tensor.to(dtype=torch.float16).unsqueeze(0)
+            n_img = len(video_frames)
+        elif args.visual_input.endswith('png') or args.visual_input.endswith('jpg'):
+            from PIL import Image
+            image = Image.open(args.visual_input)
+            data["pixel_values"] = image_processor(image, return_tensors='pt')['pixel_values'].to(dtype=torch.float16)
+            n_img = 1
+        else:
+            sys.exit("error: --visual_input must end with mp4, png or jpg")
+        data["input_ids"] = process_text(build_prompt(args.prompt, n_img), tokenizer)
+
+    model.visual_encoder.reset_tome_r(args.token_kept_ratio)
+    output = model(data, mode="inference")
+    cont = model.llm.generate(**output, do_sample=False, temperature=args.temperature, top_p=args.top_p,
+                              num_beams=args.num_beams, max_new_tokens=args.max_new_tokens)
+    if tokenizer is None:
+        print(cont[0].tolist())
+    else:
+        print(tokenizer.batch_decode(cont, skip_special_tokens=True)[0])
+
+
+if __name__ == "__main__":
+    main()

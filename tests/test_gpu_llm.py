@@ -162,3 +162,36 @@ def test_projector_splice_and_whole_path():
         assert agree >= 1
     finally:
         eng.close()
+
+
+def test_reference_operator_seam_matches_engine_path():
+    """reset_tome_r / model(data, mode='inference') / llm.generate(**output, ...) - the three calls of
+    inference.py:87-96 - give the same ids as the engine's own whole-path call, and keep the error behaviour."""
+    from aurora_amd.engine import AuroraCapEngine
+    from aurora_amd.model import AuroraModel
+    vcfg = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=4, intermediate_size=128, patch_size=14,
+                image_size=56, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    lcfg = LLM_CFGS["hd32"]
+    w = {"vit": rand_vit_weights(vcfg, 1), "projector": rand_proj_weights(64, lcfg["hidden_size"], 2), "llm": rand_llm_weights(lcfg, 3)}
+    eng = AuroraCapEngine({"vit": vcfg, "llm": lcfg}, w, max_frames=3, max_batch=1, max_ctx=256, max_new_tokens=16)
+    try:
+        m = AuroraModel(eng, eos_token_id=None)
+        px = torch.randn(1, 3, 3, 56, 56, generator=torch.Generator().manual_seed(5)).half()
+        ids = torch.tensor([[1, 17, -200, 18, -200, 19, -200, 20]])
+        m.visual_encoder.reset_tome_r(0.5)
+        out = m({"pixel_values": px, "input_ids": ids}, mode="inference")
+        assert out["input_ids"] is None and out["attention_mask"] is None and out["position_ids"] is None and out["labels"] is None
+        n_kept = out["inputs_embeds"].shape[1] - 5
+        assert out["inputs_embeds"].shape[0] == 1 and n_kept % 3 == 0
+        cont = m.llm.generate(**out, do_sample=False, temperature=0.0, top_p=1.0, num_beams=1, max_new_tokens=10)
+        assert cont.dtype == torch.long and cont.shape == (1, 10)
+        assert cont[0].tolist() == eng.caption_ids(px[0], ids[0].tolist(), 0.5, 10, eos_id=None)
+        # single image [1, c, h, w] is a one-frame video (aurora.py:217-218)
+        one = m({"pixel_values": px[:, 0], "input_ids": torch.tensor([[1, -200, 5]])}, mode="inference")
+        assert one["inputs_embeds"].shape[1] == 2 + n_kept // 3
+        with pytest.raises(NotImplementedError):
+            m({"pixel_values": px, "input_ids": ids}, mode="bogus")
+        with pytest.raises(NotImplementedError):
+            m.llm.generate(**out, do_sample=False, num_beams=4, max_new_tokens=4)
+    finally:
+        eng.close()

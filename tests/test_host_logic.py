@@ -1,0 +1,112 @@
+"""CPU tests of the host side: prompt/text processing, checkpoint mapping, clip sharding + gather (gloo, world 2)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from aurora_amd import checkpoint, model, parallel
+from oracle import aurora_oracle as O
+from tests.util import rand_llm_weights, rand_proj_weights, rand_vit_weights
+
+
+class FakeTok:
+    def encode(self, s, add_special_tokens=True):
+        return ([1] if add_special_tokens else []) + [100 + len(s)]
+
+
+def test_prompt_and_process_text_match_reference_semantics():
+    text = model.build_prompt("Describe the video in detail.", 3)
+    assert text == O.build_prompt("Describe the video in detail.", 3)
+    ids = model.process_text(text, FakeTok())
+    ref = O.process_text(text, lambda s, sp: FakeTok().encode(s, add_special_tokens=sp))
+    assert ids.shape == (1, len(ref)) and ids[0].tolist() == ref
+    assert (ids == model.IMAGE_TOKEN_INDEX).sum() == 3
+
+
+def test_checkpoint_directory_round_trip(tmp_path):
+    from safetensors.torch import save_file
+    vcfg = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, patch_size=14, image_size=56,
+                hidden_act="gelu", layer_norm_eps=1e-6)
+    lcfg = dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=256, vocab_size=320,
+                rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=4.0)
+    vw, lw, pw = rand_vit_weights(vcfg, 1), rand_llm_weights(lcfg, 2), rand_proj_weights(64, 128, 3)
+    root = tmp_path / "ckpt"
+    (root / "visual_encoder").mkdir(parents=True)
+    (root / "projector").mkdir()
+    vs = {"vision_model.embeddings.patch_embedding.weight": vw["patch_embedding.weight"],
+          "vision_model.embeddings.class_embedding": vw["class_embedding"],
+          "vision_model.embeddings.position_embedding.weight": vw["position_embedding.weight"],
+          "vision_model.pre_layrnorm.weight": vw["pre_layrnorm.weight"], "vision_model.pre_layrnorm.bias": vw["pre_layrnorm.bias"],
+          "vision_model.post_layernorm.weight": torch.ones(64), "vision_model.post_layernorm.bias": torch.zeros(64)}
+    for i, l in enumerate(vw["layers"]):
+        for k, t in l.items():
+            mod = "self_attn." if "proj" in k else ("mlp." if k.startswith("fc") else "")
+            vs[f"vision_model.encoder.layers.{i}.{mod}{k}"] = t
+    save_file({k: v.contiguous() for k, v in vs.items()}, str(root / "visual_encoder" / "model.safetensors"))
+    json.dump({"vision_config": dict(vcfg, num_channels=3)}, open(root / "visual_encoder" / "config.json", "w"))
+    ls = {"model.embed_tokens.weight": lw["embed_tokens.weight"], "model.norm.weight": lw["norm.weight"], "lm_head.weight": lw["lm_head.weight"]}
+    for i, l in enumerate(lw["layers"]):
+        for k, t in l.items():
+            mod = "self_attn." if k[0] in "qkvo" and "proj" in k else ("mlp." if "proj" in k else "")
+            ls[f"model.layers.{i}.{mod}{k}"] = t
+    save_file({k: v.contiguous() for k, v in ls.items()}, str(root / "model.safetensors"))
+    json.dump(dict(hidden_size=128, num_attention_heads=4, num_key_value_heads=4, num_hidden_layers=2, intermediate_size=256,
+                   vocab_size=320, rms_norm_eps=1e-5, rope_theta=1e4, rope_scaling={"type": "linear", "factor": 4.0},
+                   eos_token_id=2), open(root / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in pw.items()}, str(root / "projector" / "model.safetensors"))
+    json.dump({}, open(root / "projector" / "config.json", "w"))
+    cfg, w = checkpoint.load_auroracap(str(root))
+    assert cfg["vit"]["hidden_act"] == "gelu" and cfg["vit"]["layer_norm_eps"] == 1e-6        # read from config, not hard-coded
+    assert cfg["llm"]["rope_factor"] == 4.0 and cfg["llm"]["eos_token_id"] == 2
+    assert torch.equal(w["vit"]["layers"][1]["fc2.weight"], vw["layers"][1]["fc2.weight"])
+    assert torch.equal(w["llm"]["layers"][1]["down_proj.weight"], lw["layers"][1]["down_proj.weight"])
+    assert torch.equal(w["projector"]["model.2.bias"], pw["model.2.bias"])
+    # the oracle consumes the loaded dict directly (same naming)
+    px = torch.randn(1, 3, 56, 56)
+    f = O.vit_features(px, w["vit"], cfg["vit"], 0.5)
+    assert f.shape[0] == 1 and f.shape[2] == 64
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_auroracap(str(tmp_path / "nope"))
+
+
+def test_shard_and_merge_round_robin():
+    for n, world in [(64, 8), (10, 4), (3, 8), (0, 2)]:
+        shards = {r: parallel.shard_clips(n, r, world) for r in range(world)}
+        assert sorted(sum(shards.values(), [])) == list(range(n))
+        per_rank = {r: [[i, i + 1] for i in shards[r]] for r in range(world)}
+        assert parallel.merge_round_robin(per_rank, n) == [[i, i + 1] for i in range(n)]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_clips, max_new = 5, 6
+    mine = parallel.shard_clips(n_clips, rank, world)
+    local = [[c * 10 + k for k in range(1 + (c % max_new))] for c in mine]      # ragged lengths
+    per_rank = parallel.gather_results(local, max_new, clips_per_rank=3, device="cpu")
+    merged = parallel.merge_round_robin(per_rank, n_clips)
+    q.put((rank, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_results_gloo_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [[c * 10 + k for k in range(1 + (c % 6))] for c in range(5)]
+    assert res[0] == want and res[1] == want
