@@ -66,6 +66,8 @@ SIGNATURES = {
     "aur_rmsnorm": (C.c_int, [_P, _P, _I, _I, _P, C.c_float, _P, _P]),
     "aur_vit_layer": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "aur_copy_logits": (C.c_int, [_P, _P, _P]),
+    "aur_set_option": (C.c_int, [_P, C.c_char_p, _L]),
+    "aur_microbench": (C.c_int, [_P, C.c_char_p, _I, C.POINTER(C.c_double), _P]),
     "aur_profile_enable": (C.c_int, [_P, _I]),
     "aur_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_L)]),
 }

@@ -19,8 +19,8 @@
 
 #define SK_LDS_BUDGET (72 * 1024)
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a, int KC) {
+template <int NT, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a, int KC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -34,69 +34,109 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a, int KC) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kc0 = 0; kc0 < a.K; kc0 += KC) {
-        const int kc = (a.K - kc0) < KC ? (a.K - kc0) : KC;     // multiple of 128
-        const int ldxs = kc + 8;
-        if (kc0 > 0) __syncthreads();
-        // stage x[:, kc0 : kc0 + kc] into LDS (16-byte pieces)
-        {
-            const int pieces_per_row = kc >> 3;
-            for (int idx = tid; idx < a.B * pieces_per_row; idx += 256) {
-                const int b = idx / pieces_per_row, p = idx % pieces_per_row;
-                *(h8*)(xs + b * ldxs + p * 8) = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
+    // The weight stream is ONE continuous software pipeline over all of this wave's k32 tiles (wave w owns
+    // tiles w, w+4, ...): the first batch is in flight before x is staged, and it keeps running across the
+    // x-chunk boundaries (chunks exist only because B x K halves may exceed the LDS budget).
+    constexpr int U = 4;
+    const int nit = a.K / (32 * NW);             // tiles per wave (wave w owns tiles w, w+NW, ...)
+    const int tpc = KC / (32 * NW);              // tiles per wave per x-chunk (multiple of U when there are several chunks)
+    const int ldxs = KC + 8;
+    const half_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = a.W + ((int64_t)(tile0 + t) * K32 + w) * AUR_FRAG_HALVES + lane * 8;
+    const half_t* xp = xs + xrow * ldxs + w * 32 + g * 8;
+    const int nfull = nit / U * U;
+    h8 cur[U][NT], nxt[U][NT];
+    if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                cur[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)u * NW * AUR_FRAG_HALVES));
+    }
+    // fused RMSNorm prologue (HF LlamaRMSNorm): rstd per row from 16 threads per row, fixed reduction order
+    float* rs = (float*)(smem + (size_t)a.B * ldxs * 2);          // [16] row scales, after the x image
+    if (a.norm_w) {
+        const int row = tid >> 4, j = tid & 15;
+        float ss = 0.f;
+        if (row < a.B && tid < 256) {
+            const half_t* xr = a.x + (int64_t)row * a.ldx;
+            for (int p = j; p < (a.K >> 3); p += 16) {
+                const h8 v = *(const h8*)(xr + p * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
             }
         }
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64);
+        if (j == 0 && row < a.B && tid < 256) rs[row] = rsqrtf(ss / (float)a.K + a.norm_eps);
+    }
+    auto stage = [&](int chunk) {               // block-uniform: every wave calls it at the same tile index
         __syncthreads();
-        const int nit = kc >> 7;                 // k32 tiles per wave in this chunk
-        const int kt0 = (kc0 >> 5) + w;          // this wave's first k32 tile
-        const half_t* wp[NT];
+        const int kc0 = chunk * KC;
+        const int kc = (a.K - kc0) < KC ? (a.K - kc0) : KC;
+        const int ppr = kc >> 3;
+        for (int idx = tid; idx < a.B * ppr; idx += 64 * NW) {
+            const int b = idx / ppr, p = idx % ppr;
+            h8 v = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
+            if (a.norm_w) {
+                const float sc = rs[b];
+                const float* nw = a.norm_w + kc0 + p * 8;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wp[t] = a.W + ((int64_t)(tile0 + t) * K32 + kt0) * AUR_FRAG_HALVES + lane * 8;
-        const half_t* xp = xs + xrow * ldxs + w * 32 + g * 8;
-        constexpr int U = 4;
-        int i0 = 0;
-        if (nit >= U) {
-            h8 cur[U][NT], nxt[U][NT];
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)(nw[e] * (float)(half_t)((float)v[e] * sc));
+            }
+            *(h8*)(xs + b * ldxs + p * 8) = v;
+        }
+        __syncthreads();
+    };
+    int staged = -1;
+    int i0 = 0;
+    for (; i0 < nfull; i0 += U) {
+        const int chunk = i0 / tpc;
+        if (chunk != staged) {
+            stage(chunk);
+            staged = chunk;
+        }
+        const bool more = (i0 + 2 * U <= nfull);            // wave-uniform: one branch per batch
+        if (more) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    cur[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)u * 4 * AUR_FRAG_HALVES));
-            for (; i0 + U <= nit; i0 += U) {
-                const bool more = (i0 + 2 * U <= nit);        // wave-uniform: one branch per batch
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            nxt[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)(i0 + U + u) * 4 * AUR_FRAG_HALVES));
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const h8 xf = *(const h8*)(xp + (i0 + u) * 128);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[u][t], xf, acc[t]);
-                }
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) cur[u][t] = nxt[u][t];
-                }
-            }
+                    nxt[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)(i0 + U + u) * NW * AUR_FRAG_HALVES));
         }
-        for (; i0 < nit; ++i0) {           // tail (< U tiles)
-            const h8 xf = *(const h8*)(xp + i0 * 128);
+        const int il = i0 - chunk * tpc;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const h8 wf = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)i0 * 4 * AUR_FRAG_HALVES));
-                acc[t] = mfma16(wf, xf, acc[t]);
-            }
+        for (int u = 0; u < U; ++u) {
+            const h8 xf = *(const h8*)(xp + (il + u) * (32 * NW));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[u][t], xf, acc[t]);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cur[u][t] = nxt[u][t];
+        }
+    }
+    for (; i0 < nit; ++i0) {                     // tail (< U tiles)
+        const int chunk = i0 / tpc;
+        if (chunk != staged) {
+            stage(chunk);
+            staged = chunk;
+        }
+        const h8 xf = *(const h8*)(xp + (i0 - chunk * tpc) * (32 * NW));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h8 wf = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)i0 * NW * AUR_FRAG_HALVES));
+            acc[t] = mfma16(wf, xf, acc[t]);
         }
     }
     // cross-wave reduction in fixed order
     __syncthreads();
-    float* red = (float*)smem;       // [4 waves][NT][64 lanes][4]
+    float* red = (float*)smem;       // [NW waves][NT][64 lanes][4]
 #pragma unroll
     for (int t = 0; t < NT; ++t) *(f4*)(red + ((w * NT + t) * 64 + lane) * 4) = acc[t];
     __syncthreads();
@@ -105,7 +145,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a, int KC) {
     for (int t = 0; t < NT; ++t) {
         f4 s = *(const f4*)(red + ((0 * NT + t) * 64 + lane) * 4);
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
+        for (int ww = 1; ww < NW; ++ww) {
             const f4 p = *(const f4*)(red + ((ww * NT + t) * 64 + lane) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] += p[i];
@@ -183,37 +223,46 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a, int KC) {
     }
 }
 
-template <int NT, int MODE>
+template <int NT, int MODE, int NW>
 static hipError_t launch_skinny_t(const SkinnyArgs& a, hipStream_t s) {
-    // chunk K so that B x (KC + 8) halves fit the LDS budget; KC multiple of 128
+    // chunk K so that B x (KC + 8) halves fit the LDS budget; chunk boundaries fall on whole U-tile batches
+    constexpr int G = 32 * NW * 4;
     int kc = a.K;
-    const int maxk = (SK_LDS_BUDGET / (2 * a.B) - 8) & ~511;
+    const int maxk = (SK_LDS_BUDGET / (2 * a.B) - 8) / G * G;
     if (kc > maxk) {
         const int nch = (a.K + maxk - 1) / maxk;
-        kc = (((a.K + nch - 1) / nch) + 511) & ~511;
+        kc = (((a.K + nch - 1) / nch) + G - 1) / G * G;
     }
-    size_t lds = (size_t)a.B * (kc + 8) * 2;
-    const size_t red = (size_t)4 * NT * 64 * 16;
+    size_t lds = (size_t)a.B * (kc + 8) * 2 + 64;           // x image + 16 row scales (fused RMSNorm)
+    const size_t red = (size_t)NW * NT * 64 * 16;
     if (lds < red) lds = red;
-    hipLaunchKernelGGL((skinny_kernel<NT, MODE>), dim3(a.Npad / (16 * NT)), dim3(256), lds, s, a, kc);
+    hipLaunchKernelGGL((skinny_kernel<NT, MODE, NW>), dim3(a.Npad / (16 * NT)), dim3(64 * NW), lds, s, a, kc);
     return hipGetLastError();
 }
 
+template <int NT, int MODE, int NW>
+static hipError_t skinny_attr() {
+    return hipFuncSetAttribute((const void*)skinny_kernel<NT, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+}
 hipError_t skinny_init() {
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)skinny_kernel<1, SK_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)skinny_kernel<1, SK_LOGITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)skinny_kernel<2, SK_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)skinny_kernel<2, SK_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if ((e = skinny_attr<1, SK_ROW, 4>()) != hipSuccess) return e;
+    if ((e = skinny_attr<1, SK_ROW, 8>()) != hipSuccess) return e;
+    if ((e = skinny_attr<1, SK_LOGITS, 4>()) != hipSuccess) return e;
+    if ((e = skinny_attr<2, SK_SILU_MUL, 4>()) != hipSuccess) return e;
+    return skinny_attr<2, SK_QKV, 4>();
 }
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > 16 || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
     switch (a.mode) {
-        case SK_ROW: return launch_skinny_t<1, SK_ROW>(a, s);
-        case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS>(a, s);
-        case SK_SILU_MUL: return launch_skinny_t<2, SK_SILU_MUL>(a, s);
-        case SK_QKV: return launch_skinny_t<2, SK_QKV>(a, s);
+        case SK_ROW:
+            // few output tiles (N = hidden): 8 waves per workgroup double the loads in flight per CU
+            if (a.waves == 8 && (a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8>(a, s);
+            return launch_skinny_t<1, SK_ROW, 4>(a, s);
+        case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS, 4>(a, s);
+        case SK_SILU_MUL: return launch_skinny_t<2, SK_SILU_MUL, 4>(a, s);
+        case SK_QKV: return launch_skinny_t<2, SK_QKV, 4>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -315,6 +364,109 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecAttnArgs a) {
     }
 }
 
+// Variant 1: software-pipelined over 64-token pages.  While page p is being reduced (QK^T -> softmax -> PV),
+// its V fragments and page p+1's K fragments are already in flight (32 KiB per wave), so a wave never
+// idles for a full HBM round trip between its MFMA bursts.  Requires page_tokens == 64.
+template <int KBLK, int VD16>
+__global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;
+    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const KvLayout& kv = a.kv;
+    const int npos = a.pos[b] + 1;
+    const int seq = a.seq_ids ? a.seq_ids[b] : b;
+    const int npages = (npos + 63) >> 6;
+    const int p_first = sp * a.pages_per_split;
+    int p_last = p_first + a.pages_per_split;
+    p_last = p_last < npages ? p_last : npages;
+    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
+
+    h8 qf[KBLK];
+#pragma unroll
+    for (int blk = 0; blk < KBLK; ++blk)
+        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
+    f4 acc_o[VD16];
+#pragma unroll
+    for (int d = 0; d < VD16; ++d) acc_o[d] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale * 1.4426950408889634f;
+    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;        // K frags of a (page, head): 4*KBLK contiguous KiB
+    const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;        // V frags: VD16*2 contiguous KiB
+
+    h8 kf[4 * KBLK], kn[4 * KBLK];
+    if (p_first < p_last) {
+        const half_t* page = kv_page(kv, seq, p_first * 64);
+#pragma unroll
+        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
+    }
+    for (int p = p_first; p < p_last; ++p) {
+        const half_t* page = kv_page(kv, seq, p * 64);
+        h8 vf[VD16 * 2];
+#pragma unroll
+        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
+        const bool more = p + 1 < p_last;                 // wave-uniform
+        if (more) {
+            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 4 * KBLK; ++i) kn[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
+        }
+        const int key0 = p * 64;
+        f4 s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < KBLK; ++blk) s[kt] = mfma16(kf[kt * KBLK + blk], qf[blk], s[kt]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = key0 + kt * 16 + 4 * g + i;
+                const float v = key < npos ? s[kt][i] * sc : -INFINITY;
+                s[kt][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        h8 pf[2];
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][i] - m_new);
+                ps += pv;
+                pf[kt >> 1][(kt & 1) * 4 + i] = (half_t)pv;
+            }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_o[d][i] *= alpha;
+            acc_o[d] = mfma16(vf[d * 2 + 0], pf[0], acc_o[d]);
+            acc_o[d] = mfma16(vf[d * 2 + 1], pf[1], acc_o[d]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = kn[i];
+        }
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
+    }
+    if (lane == 0) {
+        a.part_ml[pidx * 2 + 0] = m_run;
+        a.part_ml[pidx * 2 + 1] = l;
+    }
+}
+
 __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     if (d >= a.hd) return;
@@ -335,7 +487,11 @@ __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
     if (a.kv.page_tokens & 63) return hipErrorInvalidValue;
     dim3 grid(a.nsplit, a.heads, a.B);
-    if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    const bool pipe = a.variant == 1 && a.kv.page_tokens == 64;
+    if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    else if (pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_pipe_kernel<2, 4>), grid, dim3(64), 0, s, a);
+    else if (pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_pipe_kernel<1, 2>), grid, dim3(64), 0, s, a);
+    else if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_kernel<1, 2>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;

@@ -67,6 +67,7 @@ struct aur_ctx {
     int32_t *s_pos, *s_ids, *s_len, *s_fin, *s_ptab;
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
+    int fuse_norm = 0, attn_variant = 1, row_waves = 8, last_prefill_len = 0;      // tuning knobs (aur_set_option)
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     // profiling
@@ -199,8 +200,8 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_attn = k.take<half_t>(B * d);
     c->d_h = k.take<half_t>(B * g.llm_mlp);
     c->d_logits = k.take<float>(B * g.llm_vocab);
-    c->d_part_o = k.take<float>(B * g.llm_heads * c->nsplit * c->l_hd);
-    c->d_part_ml = k.take<float>(B * g.llm_heads * c->nsplit * 2);
+    c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
+    c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_pos = k.take<int32_t>(B);
     c->s_ids = k.take<int32_t>(B * g.max_new_tokens);
     c->s_len = k.take<int32_t>(B);
@@ -714,6 +715,48 @@ static int lm_head_and_advance(aur_ctx* ctx, const half_t* xn, int b0, int nb, i
     return AUR_OK;
 }
 
+// One prefill layer; `which` selects the kernels (bit 0 norm1, 1 qkv, 2 attention, 3 o_proj, 4 norm2, 5 gate/up, 6 down)
+// so that aur_microbench can time each of them in isolation.
+static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, half_t* x, int seq_len, hipStream_t s) {
+    const aur_config& g = ctx->cfg;
+    const LlmLayerW& w = ctx->ll[l];
+    const int d = g.llm_hidden, M = rup(seq_len, 32);
+    if (which & 1) CK(launch_rmsnorm(x, d, w.ln1_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+    if (which & 2) {
+        GemmArgs q{};
+        q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
+        q.rows_per_seq = M; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
+        q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot;
+        CK(launch_gemm(q, EPI_QKV, s));
+    }
+    if (which & 4) {
+        AttnArgs at{};
+        at.Qf = ctx->l_qf; at.kv = llm_kv(ctx, l); at.seq0 = slot; at.nseq = 1; at.heads = g.llm_heads; at.rows_per_seq = M; at.t = seq_len;
+        at.causal = 1; at.scale = 1.0f / sqrtf((float)ctx->l_hd); at.O = ctx->l_attn; at.ldo = d; at.hd = ctx->l_hd;
+        CK(launch_attention(at, s));
+    }
+    if (which & 8) {
+        GemmArgs o{};
+        o.A = ctx->l_attn; o.lda = d; o.W = w.o_w; o.M = M; o.Npad = ctx->l_dpad; o.K = d; o.C = x; o.ldc = d; o.resid = x; o.ldr = d;
+        o.n_real = d; o.act = ACT_NONE;
+        CK(launch_gemm(o, EPI_ROW, s));
+    }
+    if (which & 16) CK(launch_rmsnorm(x, d, w.ln2_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+    if (which & 32) {
+        GemmArgs gu{};
+        gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
+        gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL;
+        CK(launch_gemm(gu, EPI_ROW, s));
+    }
+    if (which & 64) {
+        GemmArgs dn{};
+        dn.A = ctx->l_h; dn.lda = g.llm_mlp; dn.W = w.down_w; dn.M = M; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.C = x; dn.ldc = d;
+        dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE;
+        CK(launch_gemm(dn, EPI_ROW, s));
+    }
+    return AUR_OK;
+}
+
 extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
     if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_prefill: language weights not finalized");
     const aur_config& g = ctx->cfg;
@@ -721,33 +764,12 @@ extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t
     if (seq_len < 1 || seq_len + ctx->max_new > g.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, g.max_ctx);
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "prefill", s);
-    const int d = g.llm_hidden, M = rup(seq_len, 32);
+    const int d = g.llm_hidden;
     half_t* x = (half_t*)embeds;
+    ctx->last_prefill_len = seq_len;
     for (int l = 0; l < g.llm_layers; ++l) {
-        const LlmLayerW& w = ctx->ll[l];
-        CK(launch_rmsnorm(x, d, w.ln1_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
-        GemmArgs q{};
-        q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
-        q.rows_per_seq = M; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
-        q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot;
-        CK(launch_gemm(q, EPI_QKV, s));
-        AttnArgs at{};
-        at.Qf = ctx->l_qf; at.kv = q.kv; at.seq0 = slot; at.nseq = 1; at.heads = g.llm_heads; at.rows_per_seq = M; at.t = seq_len;
-        at.causal = 1; at.scale = 1.0f / sqrtf((float)ctx->l_hd); at.O = ctx->l_attn; at.ldo = d; at.hd = ctx->l_hd;
-        CK(launch_attention(at, s));
-        GemmArgs o{};
-        o.A = ctx->l_attn; o.lda = d; o.W = w.o_w; o.M = M; o.Npad = ctx->l_dpad; o.K = d; o.C = x; o.ldc = d; o.resid = x; o.ldr = d;
-        o.n_real = d; o.act = ACT_NONE;
-        CK(launch_gemm(o, EPI_ROW, s));
-        CK(launch_rmsnorm(x, d, w.ln2_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
-        GemmArgs gu{};
-        gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
-        gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL;
-        CK(launch_gemm(gu, EPI_ROW, s));
-        GemmArgs dn{};
-        dn.A = ctx->l_h; dn.lda = g.llm_mlp; dn.W = w.down_w; dn.M = M; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.C = x; dn.ldc = d;
-        dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE;
-        CK(launch_gemm(dn, EPI_ROW, s));
+        int rc = prefill_layer(ctx, l, 0x7f, slot, x, seq_len, s);
+        if (rc) return rc;
     }
     // logits of the last prompt position -> first generated token
     half_t* xn1 = ctx->d_xn + (int64_t)slot * d;
@@ -758,30 +780,61 @@ extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t
     return AUR_OK;
 }
 
+// ---- decode-step kernel argument builders (shared by the step and by aur_microbench)
+static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
+    const aur_config& g = ctx->cfg;
+    const int d = g.llm_hidden;
+    SkinnyArgs q{};
+    q.x = ctx->fuse_norm ? ctx->d_x : ctx->d_xn; q.ldx = d; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
+    q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr;
+    if (ctx->fuse_norm) { q.norm_w = ctx->ll[l].ln1_w; q.norm_eps = g.llm_rms_eps; }
+    return q;
+}
+static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
+    const aur_config& g = ctx->cfg;
+    DecAttnArgs at{};
+    at.qbuf = ctx->d_q; at.kv = llm_kv(ctx, l); at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = ctx->batch; at.heads = g.llm_heads;
+    at.hd = ctx->l_hd; at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
+    at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out = ctx->d_attn; at.ldo = g.llm_hidden; at.variant = ctx->attn_variant;
+    return at;
+}
+static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
+    const int d = ctx->cfg.llm_hidden;
+    SkinnyArgs o{};
+    o.x = ctx->d_attn; o.ldx = d; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d; o.mode = SK_ROW;
+    o.out = ctx->d_x; o.ldo = d; o.resid = ctx->d_x; o.ldr = d; o.waves = ctx->row_waves;
+    return o;
+}
+static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
+    const aur_config& g = ctx->cfg;
+    const int d = g.llm_hidden;
+    SkinnyArgs gu{};
+    gu.x = ctx->fuse_norm ? ctx->d_x : ctx->d_xn; gu.ldx = d; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out = ctx->d_h; gu.ldo = g.llm_mlp;
+    if (ctx->fuse_norm) { gu.norm_w = ctx->ll[l].ln2_w; gu.norm_eps = g.llm_rms_eps; }
+    return gu;
+}
+static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
+    const aur_config& g = ctx->cfg;
+    const int d = g.llm_hidden;
+    SkinnyArgs dn{};
+    dn.x = ctx->d_h; dn.ldx = g.llm_mlp; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.n_real = d;
+    dn.mode = SK_ROW; dn.out = ctx->d_x; dn.ldo = d; dn.resid = ctx->d_x; dn.ldr = d; dn.waves = ctx->row_waves;
+    return dn;
+}
+
 static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden, B = ctx->batch;
     for (int l = 0; l < g.llm_layers; ++l) {
         const LlmLayerW& w = ctx->ll[l];
-        CK(launch_rmsnorm(ctx->d_x, d, w.ln1_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
-        SkinnyArgs q{};
-        q.x = ctx->d_xn; q.ldx = d; q.W = w.qkv_w; q.B = B; q.Npad = ctx->l_qkv_npad; q.K = d; q.n_real = 3 * d; q.mode = SK_QKV;
-        q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l); q.rope = ctx->l_rope; q.pos = ctx->s_pos;
-        q.seq_ids = nullptr;
-        CK(launch_skinny(q, s));
-        DecAttnArgs at{};
-        at.qbuf = ctx->d_q; at.kv = q.kv; at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = B; at.heads = g.llm_heads; at.hd = ctx->l_hd;
-        at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
-        at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out = ctx->d_attn; at.ldo = d;
-        CK(launch_decode_attention(at, s));
-        SkinnyArgs o{};
-        o.x = ctx->d_attn; o.ldx = d; o.W = w.o_w; o.B = B; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d; o.mode = SK_ROW;
-        o.out = ctx->d_x; o.ldo = d; o.resid = ctx->d_x; o.ldr = d;
-        CK(launch_skinny(o, s));
-        CK(launch_rmsnorm(ctx->d_x, d, w.ln2_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
-        SkinnyArgs gu{};
-        gu.x = ctx->d_xn; gu.ldx = d; gu.W = w.gateup_w; gu.B = B; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.n_real = 2 * g.llm_mlp;
-        gu.mode = SK_SILU_MUL; gu.out = ctx->d_h; gu.ldo = g.llm_mlp;
+        if (!ctx->fuse_norm) CK(launch_rmsnorm(ctx->d_x, d, w.ln1_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
+        CK(launch_skinny(mk_dec_qkv(ctx, l), s));
+        CK(launch_decode_attention(mk_dec_attn(ctx, l), s));
+        CK(launch_skinny(mk_dec_o(ctx, l), s));
+        if (!ctx->fuse_norm) CK(launch_rmsnorm(ctx->d_x, d, w.ln2_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
+        SkinnyArgs gu = mk_dec_gateup(ctx, l);
         if (instrument) {
             if (ctx->kev_used == ctx->kev.size()) {
                 hipEvent_t a, b;
@@ -797,10 +850,7 @@ static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
             ctx->kev_used++;
             if (ctx->kev_used >= 4096) kev_fold(ctx);
         }
-        SkinnyArgs dn{};
-        dn.x = ctx->d_h; dn.ldx = g.llm_mlp; dn.W = w.down_w; dn.B = B; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.n_real = d;
-        dn.mode = SK_ROW; dn.out = ctx->d_x; dn.ldo = d; dn.resid = ctx->d_x; dn.ldr = d;
-        CK(launch_skinny(dn, s));
+        CK(launch_skinny(mk_dec_down(ctx, l), s));
     }
     CK(launch_rmsnorm(ctx->d_x, d, ctx->l_norm_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
     return lm_head_and_advance(ctx, ctx->d_xn, 0, B, 1, -1, s);
@@ -860,5 +910,69 @@ extern "C" int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream) {
 extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
     if (ctx->batch < 1 || !dst_dev) return aur_fail(ctx, AUR_ERR_STATE, "aur_copy_logits: no active batch");
     CK(hipMemcpyAsync(dst_dev, ctx->d_logits, (size_t)ctx->batch * ctx->cfg.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ tuning / microbench
+extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
+    if (!strcmp(name, "fuse_norm")) ctx->fuse_norm = value != 0;
+    else if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
+    else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
+    else if (!strcmp(name, "dec_attn_pps")) {
+        if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
+        ctx->pps = (int)value;
+        ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
+    } else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
+    if (ctx->graph) {             // kernel arguments are frozen in the captured graph
+        hipGraphExecDestroy(ctx->graph);
+        ctx->graph = nullptr;
+    }
+    return AUR_OK;
+}
+
+// Time ONE kernel of the path in isolation on the current generation state (after aur_llm_prefill): `iters`
+// back-to-back launches cycling through the layers (so weights stream from HBM, not from the 256 MiB MALL),
+// bracketed by HIP events on `stream`.  Synchronises.  us_out = mean microseconds per launch.
+extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, double* us_out, void* stream) {
+    if (!ctx->finalized || ctx->ll.empty() || ctx->batch < 1 || ctx->last_prefill_len < 1)
+        return aur_fail(ctx, AUR_ERR_STATE, "aur_microbench: prefill a batch first");
+    hipStream_t s = (hipStream_t)stream;
+    const aur_config& g = ctx->cfg;
+    const int nl = g.llm_layers, d = g.llm_hidden;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto run = [&](int i) -> int {
+        const int l = i % nl;
+        if (!strcmp(kernel, "dec_norm")) { CK(launch_rmsnorm(ctx->d_x, d, ctx->ll[l].ln1_w, g.llm_rms_eps, ctx->batch, d, ctx->d_xn, d, s)); }
+        else if (!strcmp(kernel, "dec_qkv")) { CK(launch_skinny(mk_dec_qkv(ctx, l), s)); }
+        else if (!strcmp(kernel, "dec_attn")) { CK(launch_decode_attention(mk_dec_attn(ctx, l), s)); }
+        else if (!strcmp(kernel, "dec_o")) { CK(launch_skinny(mk_dec_o(ctx, l), s)); }
+        else if (!strcmp(kernel, "dec_gateup")) { CK(launch_skinny(mk_dec_gateup(ctx, l), s)); }
+        else if (!strcmp(kernel, "dec_down")) { CK(launch_skinny(mk_dec_down(ctx, l), s)); }
+        else if (!strcmp(kernel, "dec_lm_head")) {
+            SkinnyArgs h{};
+            h.x = ctx->d_xn; h.ldx = d; h.W = ctx->l_head_w; h.B = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = d; h.n_real = g.llm_vocab;
+            h.mode = SK_LOGITS; h.out32 = ctx->d_logits;
+            CK(launch_skinny(h, s));
+        } else {
+            int bit = !strcmp(kernel, "pre_norm") ? 1 : !strcmp(kernel, "pre_qkv") ? 2 : !strcmp(kernel, "pre_attn") ? 4 : !strcmp(kernel, "pre_o") ? 8
+                      : !strcmp(kernel, "pre_gateup") ? 32 : !strcmp(kernel, "pre_down") ? 64 : 0;
+            if (!bit) return aur_fail(ctx, AUR_ERR_ARG, "unknown kernel '%s'", kernel);
+            // scratch residual stream: l_p1 (projector scratch) is free after the splice
+            return prefill_layer(ctx, l, bit, 0, ctx->l_p1, ctx->last_prefill_len, s);
+        }
+        return AUR_OK;
+    };
+    for (int i = 0; i < 3; ++i) { int rc = run(i); if (rc) return rc; }
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) { int rc = run(i + 3); if (rc) return rc; }
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *us_out = 1e3 * ms / iters;
     return AUR_OK;
 }

@@ -111,6 +111,9 @@ struct SkinnyArgs {
     const half_t* resid;    // optional [B, ldr]
     int ldr;
     float* out32;           // SK_LOGITS: [B, n_real] fp32
+    const float* norm_w;    // optional fused RMSNorm over x rows (weight [K]); requires the row length == K
+    float norm_eps;
+    int waves;              // SK_ROW: 4 (default) or 8 waves per workgroup
     // SK_QKV
     int q_cols, k_cols, hd;
     half_t* qbuf;           // [B][heads][kblk][4][8]   (PAIRED-d pieces)
@@ -134,6 +137,7 @@ struct DecAttnArgs {
     float* part_ml;         // [B][heads][nsplit][2]
     half_t* out;            // [B, heads*hd]
     int ldo;
+    int variant;            // 0: load-use per page; 1: software-pipelined (next page's K + this page's V in flight)
 };
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);
 

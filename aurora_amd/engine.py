@@ -434,6 +434,14 @@ class AuroraCapEngine:
         torch.cuda.synchronize()
         return xo, so, me, dict(r=rl, node_idx=ni, unm_idx=un[:, : ta - rl], src_idx=sr[:, :rl], dst_idx=ds[:, :rl])
 
+    def set_option(self, name: str, value: int):
+        check(self.ctx, self.L.aur_set_option(self.ctx, name.encode(), int(value)), "aur_set_option")
+
+    def microbench(self, kernel: str, iters: int = 200) -> float:
+        us = C.c_double(0)
+        check(self.ctx, self.L.aur_microbench(self.ctx, kernel.encode(), iters, C.byref(us), self._stream()), "aur_microbench")
+        return us.value
+
     # ------------------------------------------------------------------ profiling
     def profile(self, on: bool):
         check(self.ctx, self.L.aur_profile_enable(self.ctx, int(on)), "aur_profile_enable")

@@ -146,6 +146,14 @@ int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size,
 /* Copy the last-position logits of the most recent prefill / decode step into dst_dev: fp32 [batch, vocab]. */
 int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 
+/* Tuning knobs (invalidate the captured decode graph): "fuse_norm" 0/1, "dec_attn_variant" 0/1,
+ * "dec_attn_pps" pages per decode-attention split. */
+int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
+/* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
+ * kernel in {dec_norm, dec_qkv, dec_attn, dec_o, dec_gateup, dec_down, dec_lm_head, pre_norm, pre_qkv, pre_attn,
+ * pre_o, pre_gateup, pre_down}; mean microseconds per launch over `iters` launches cycling through the layers. */
+int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, double* us_out, void* stream);
+
 /* Per-stage kernel-time accounting (HIP events on the caller's stream): enable, run, read back
  * milliseconds for "vit", "project", "prefill", "decode" - and the dominant decode GEMM kernel. */
 int aur_profile_enable(aur_ctx* ctx, int32_t on);

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks of the LLM half of the path at AuroraCap-7B dims (aur_microbench).
+
+    python tools/microbench.py --batch 8 [--ctx 2142]
+
+Prints mean microseconds per launch and the achieved algorithmic GB/s (HBM-bound kernels) or TFLOP/s
+(MFMA-bound kernels) for a few tuning-knob settings.  Launches cycle through all 32 layers, so weights
+stream from HBM exactly as in a real decode step.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ctx", type=int, default=2142)
+    ap.add_argument("--iters", type=int, default=320)
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine, _rup
+    l = S.VICUNA_7B_16K
+    B, L0 = args.batch, args.ctx
+    eng = AuroraCapEngine({"vit": None, "llm": l}, {"llm": S.llm_weights(l)}, max_frames=1, max_batch=B,
+                          max_ctx=_rup(L0 + 256, 64), max_new_tokens=256)
+    torch.cuda.empty_cache()
+    d, mlp, V, H = l["hidden_size"], l["intermediate_size"], l["vocab_size"], l["num_attention_heads"]
+    eng.begin_batch(B, 256, None)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for b in range(B):
+        emb = (torch.randn(_rup(L0, 32), d, generator=g, device="cuda") * 0.02).half()
+        eng.prefill(b, emb, L0)
+    torch.cuda.synchronize()
+    M = _rup(L0, 32)
+    kv_bytes = B * (L0 + 1) * 2 * d * 2
+    work = {   # kernel -> (unit, amount per launch)
+        "dec_norm": ("GB/s", 2 * B * d * 2),
+        "dec_qkv": ("GB/s", 3 * d * d * 2), "dec_o": ("GB/s", d * d * 2), "dec_gateup": ("GB/s", 2 * mlp * d * 2),
+        "dec_down": ("GB/s", mlp * d * 2), "dec_lm_head": ("GB/s", V * d * 2), "dec_attn": ("GB/s", kv_bytes),
+        "pre_qkv": ("TF/s", 2 * M * 3 * d * d), "pre_o": ("TF/s", 2 * M * d * d), "pre_gateup": ("TF/s", 2 * M * 2 * mlp * d),
+        "pre_down": ("TF/s", 2 * M * mlp * d), "pre_attn": ("TF/s", 2 * L0 * L0 * d), "pre_norm": ("GB/s", 2 * M * d * 2),
+    }
+    res = {}
+
+    def run(tag, kernels):
+        for k in kernels:
+            if args.only and args.only not in k:
+                continue
+            us = eng.microbench(k, args.iters if k.startswith("dec") else 64)
+            unit, amt = work[k]
+            rate = amt / us / (1e3 if unit == "GB/s" else 1e6)
+            res[f"{tag}:{k}"] = (round(us, 2), round(rate, 1), unit)
+            print(f"{tag:28s} {k:12s} {us:9.2f} us  {rate:9.1f} {unit}", flush=True)
+
+    dec = ["dec_norm", "dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
+    eng.set_option("fuse_norm", 0)
+    run("unfused-norm", dec)
+    for nw in (4, 8):
+        eng.set_option("dec_row_waves", nw)
+        run(f"row kernels {nw} waves", ["dec_o", "dec_down"])
+    if not args.quick:
+        eng.set_option("fuse_norm", 1)
+        run("fused-norm", ["dec_qkv", "dec_gateup"])
+        eng.set_option("fuse_norm", 0)
+        for variant in (0, 1):
+            eng.set_option("dec_attn_variant", variant)
+            for pps in (1, 2, 4, 8):
+                eng.set_option("dec_attn_pps", pps)
+                run(f"attn v{variant} pps{pps}", ["dec_attn"])
+    else:
+        run("attn v1 pps4", ["dec_attn"])
+    run("prefill", ["pre_norm", "pre_qkv", "pre_attn", "pre_o", "pre_gateup", "pre_down"])
+    print(json.dumps(res))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
