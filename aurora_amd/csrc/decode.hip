@@ -54,40 +54,43 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a, int KC) {
             for (int t = 0; t < NT; ++t)
                 cur[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)u * NW * AUR_FRAG_HALVES));
     }
-    // fused RMSNorm prologue (HF LlamaRMSNorm): rstd per row from 16 threads per row, fixed reduction order
-    float* rs = (float*)(smem + (size_t)a.B * ldxs * 2);          // [16] row scales, after the x image
-    if (a.norm_w) {
-        const int row = tid >> 4, j = tid & 15;
-        float ss = 0.f;
-        if (row < a.B && tid < 256) {
-            const half_t* xr = a.x + (int64_t)row * a.ldx;
-            for (int p = j; p < (a.K >> 3); p += 16) {
-                const h8 v = *(const h8*)(xr + p * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
-            }
-        }
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
-        ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 8, 64);
-        if (j == 0 && row < a.B && tid < 256) rs[row] = rsqrtf(ss / (float)a.K + a.norm_eps);
-    }
+    // Fused RMSNorm (HF LlamaRMSNorm) at zero extra passes: y = rstd[b] * sum_k W[n,k] * (w_norm[k] * x[b,k]).
+    // The staging pass multiplies by w_norm and accumulates sum(x^2) per row on the fly; rstd[b] scales the
+    // accumulators in the epilogue.  Row b is staged and summed by wave (b mod NW) alone: lane partials over pieces
+    // lane, lane+64, ... in chunk order, then a fixed butterfly - the same arithmetic for any batch size.
+    const size_t x_bytes = (size_t)a.B * ldxs * 2, red_bytes = (size_t)NW * NT * 64 * 16;
+    float* rs = (float*)(smem + (x_bytes > red_bytes ? x_bytes : red_bytes));   // [16] sum(x^2) per row
     auto stage = [&](int chunk) {               // block-uniform: every wave calls it at the same tile index
         __syncthreads();
         const int kc0 = chunk * KC;
         const int kc = (a.K - kc0) < KC ? (a.K - kc0) : KC;
         const int ppr = kc >> 3;
-        for (int idx = tid; idx < a.B * ppr; idx += 64 * NW) {
-            const int b = idx / ppr, p = idx % ppr;
-            h8 v = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
-            if (a.norm_w) {
-                const float sc = rs[b];
-                const float* nw = a.norm_w + kc0 + p * 8;
+        if (a.norm_w) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)(nw[e] * (float)(half_t)((float)v[e] * sc));
+            for (int rr = 0; rr < 16 / NW; ++rr) {
+                const int b = w + rr * NW;               // wave-uniform
+                if (b < a.B) {
+                    float ss = 0.f;
+                    for (int p = lane; p < ppr; p += 64) {
+                        h8 v = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
+                        const float* nw = a.norm_w + kc0 + p * 8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xv = (float)v[e];
+                            ss += xv * xv;
+                            v[e] = (half_t)(nw[e] * xv);
+                        }
+                        *(h8*)(xs + b * ldxs + p * 8) = v;
+                    }
+                    ss = wave_sum(ss);
+                    if (lane == 0) rs[b] = (chunk == 0 ? 0.f : rs[b]) + ss;
+                }
             }
-            *(h8*)(xs + b * ldxs + p * 8) = v;
+        } else {
+            for (int idx = tid; idx < a.B * ppr; idx += 64 * NW) {
+                const int b = idx / ppr, p = idx % ppr;
+                *(h8*)(xs + b * ldxs + p * 8) = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
+            }
         }
         __syncthreads();
     };
@@ -154,6 +157,13 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a, int KC) {
     }
     const int b = c;
     if (b >= a.B) return;
+    if (a.norm_w) {                                   // fused RMSNorm: per-row 1/rms applied to the contraction
+        const float rstd = rsqrtf(rs[b] / (float)a.K + a.norm_eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i] *= rstd;
+    }
 
     if (MODE == SK_ROW || MODE == SK_LOGITS || MODE == SK_SILU_MUL) {
 #pragma unroll
@@ -233,9 +243,10 @@ static hipError_t launch_skinny_t(const SkinnyArgs& a, hipStream_t s) {
         const int nch = (a.K + maxk - 1) / maxk;
         kc = (((a.K + nch - 1) / nch) + G - 1) / G * G;
     }
-    size_t lds = (size_t)a.B * (kc + 8) * 2 + 64;           // x image + 16 row scales (fused RMSNorm)
+    size_t lds = (size_t)a.B * (kc + 8) * 2;                // x image
     const size_t red = (size_t)NW * NT * 64 * 16;
     if (lds < red) lds = red;
+    lds += 64;                                              // 16 row sums (fused RMSNorm), after both regions
     hipLaunchKernelGGL((skinny_kernel<NT, MODE, NW>), dim3(a.Npad / (16 * NT)), dim3(64 * NW), lds, s, a, kc);
     return hipGetLastError();
 }
