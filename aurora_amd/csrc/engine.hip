@@ -137,9 +137,9 @@ static void derive(aur_ctx* c) {
     c->v_kblk = c->v_hd_pad / 32;
     c->v_vd16 = c->v_hd / 16;
     c->v_qcols = rup(g.vit_heads * c->v_hd_pad, 64);
-    c->v_qkv_npad = rup(2 * c->v_qcols + g.vit_heads * c->v_hd, 128);
-    c->v_dpad = rup(g.vit_hidden, 128);
-    c->v_mlp_pad = rup(g.vit_mlp, 128);
+    c->v_qkv_npad = rup(2 * c->v_qcols + g.vit_heads * c->v_hd, 256);
+    c->v_dpad = rup(g.vit_hidden, 256);
+    c->v_mlp_pad = rup(g.vit_mlp, 256);
     const int gw = g.vit_image / g.vit_patch;
     c->v_npatch = gw * gw;
     c->v_t0 = c->v_npatch + 1;
@@ -148,10 +148,10 @@ static void derive(aur_ctx* c) {
     c->l_hd = g.llm_hidden / g.llm_heads;
     c->l_kblk = c->l_hd / 32;
     c->l_vd16 = c->l_hd / 16;
-    c->l_qkv_npad = rup(3 * g.llm_hidden, 128);
-    c->l_gu_npad = rup(2 * g.llm_mlp, 128);
-    c->l_dpad = rup(g.llm_hidden, 128);
-    c->l_vocab_pad = rup(g.llm_vocab, 128);
+    c->l_qkv_npad = rup(3 * g.llm_hidden, 256);
+    c->l_gu_npad = rup(2 * g.llm_mlp, 256);
+    c->l_dpad = rup(g.llm_hidden, 256);
+    c->l_vocab_pad = rup(g.llm_vocab, 256);
     c->l_max_pages = (g.max_ctx + g.page_tokens - 1) / g.page_tokens;
     c->l_ctx_pad = c->l_max_pages * g.page_tokens;
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
@@ -224,7 +224,7 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
     {
         hipError_t e;
         if ((e = gemm_init()) != hipSuccess || (e = attn_init()) != hipSuccess || (e = tome_init()) != hipSuccess ||
-            (e = skinny_init()) != hipSuccess)
+            (e = skinny_init()) != hipSuccess || (e = gemm256_init()) != hipSuccess)
             return aur_fail(nullptr, AUR_ERR_HIP, "kernel attribute init failed (is a gfx950 GPU visible?): %s", hipGetErrorString(e));
     }
     aur_ctx* c = new aur_ctx();
@@ -918,6 +918,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "fuse_norm")) ctx->fuse_norm = value != 0;
     else if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
+    else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
     else if (!strcmp(name, "dec_attn_pps")) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;

@@ -35,6 +35,11 @@ hipError_t attn_init();
 hipError_t tome_init();
 hipError_t skinny_init();
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+// gemm256.hip: 256x256x64 staggered two-group kernel for large shapes (auto-selected by launch_gemm)
+hipError_t gemm256_init();
+bool gemm256_eligible(const GemmArgs& a);
+hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
+void gemm_set_mode(int mode);      // 0: 128x128 kernel only, 1: auto (default), 2: force 256 when Npad % 256 == 0
 hipError_t launch_pack_weight(const half_t* w, int n_src, int k_src, int ld_src, const int32_t* row_map, int npad,
                               int kpad, half_t* out, hipStream_t s);
 

@@ -161,8 +161,8 @@ class AuroraCapEngine:
         hd = D // H
         hdp = _rup(hd, 32)
         qcols = _rup(H * hdp, 64)
-        npad = _rup(2 * qcols + D, 128)
-        dpad, mpad = _rup(D, 128), _rup(mlp, 128)
+        npad = _rup(2 * qcols + D, 256)
+        dpad, mpad = _rup(D, 256), _rup(mlp, 256)
         P, Cn = v["patch_size"], v.get("num_channels", 3)
         kpad = _rup(Cn * P * P, 64)
         # fused QKV row map: Q and K heads padded hd -> hd_pad (zero rows), V natural
@@ -214,7 +214,7 @@ class AuroraCapEngine:
     def _load_llm(self, w: dict):
         l = self.l
         d, H, mlp, V = l["hidden_size"], l["num_attention_heads"], l["intermediate_size"], l["vocab_size"]
-        qkv_npad, gu_npad, dpad, vpad = _rup(3 * d, 128), _rup(2 * mlp, 128), _rup(d, 128), _rup(V, 128)
+        qkv_npad, gu_npad, dpad, vpad = _rup(3 * d, 256), _rup(2 * mlp, 256), _rup(d, 256), _rup(V, 256)
         rm_qkv = self.llama_qkv_row_map(d, H, qkv_npad)
         rm_gu = np.full(gu_npad, -1, np.int32)
         rm_gu[0: 2 * mlp: 2] = np.arange(mlp)
@@ -235,7 +235,7 @@ class AuroraCapEngine:
 
     def _load_projector(self, w: dict):
         d, dv = self.l["hidden_size"], self.v["hidden_size"]
-        dpad = _rup(d, 128)
+        dpad = _rup(d, 256)
         self._set("proj.fc1.w", self.pack(w["model.0.weight"], dpad, dv))
         self._set("proj.fc1.b", self._bias(w["model.0.bias"], dpad))
         self._set("proj.fc2.w", self.pack(w["model.2.weight"], dpad, d))
@@ -373,7 +373,7 @@ class AuroraCapEngine:
     def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
                resid: Optional[torch.Tensor] = None) -> torch.Tensor:
         n, k = w.shape
-        npad = _rup(n, 128)
+        npad = _rup(n, 256)
         wp = self.pack(w, npad, k)
         b = self._bias(bias, npad) if bias is not None else None
         ah = self._h(a)
@@ -387,7 +387,7 @@ class AuroraCapEngine:
 
     def linear_skinny(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         n, k = w.shape
-        npad = _rup(n, 128)
+        npad = _rup(n, 256)
         wp = self.pack(w, npad, k)
         ah = self._h(a)
         out = torch.empty(ah.shape[0], n, dtype=torch.float32, device=self.dev)

@@ -177,3 +177,40 @@ def test_tome_double_run_bitwise(eng):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
         assert torch.equal(a[2][k], b[2][k])
+
+
+# ----------------------------------------------------------------------------------------------- 256x256 staggered GEMM
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (77, 256, 1280), (1000, 1280, 640), (2142, 512, 4096), (513, 768, 128), (300, 384, 192)])
+def test_gemm256_forced_matches_fp32(eng, m, n, k):
+    """Same contract as the 128x128 kernel; exercises K-tile counts 1, 2, 3, odd/even, M tails, every epilogue."""
+    eng.set_option("gemm_mode", 2)
+    try:
+        g = torch.Generator().manual_seed(m * 5 + n + k)
+        a = (torch.randn(m, k, generator=g) * 0.5).half()
+        w = (torch.randn(n, k, generator=g) * 0.05).half()
+        b = (torch.randn(n, generator=g) * 0.1).half()
+        res = torch.randn(m, n, generator=g).half()
+        ref = a.float() @ w.float().T + b.float()
+        out = eng.linear(a, w, b).float().cpu()
+        assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+        from aurora_amd._lib import AUR_ACT_GELU
+        np.testing.assert_allclose(eng.linear(a, w, b, act=AUR_ACT_GELU, resid=None).float().cpu(), torch.nn.functional.gelu(ref), rtol=2e-3, atol=3e-3)
+        np.testing.assert_allclose(eng.linear(a, w, b, resid=res).float().cpu(), ref + res.float(), rtol=2e-3, atol=5e-3)
+        # bitwise repeatability (race screen for the staggered LDS-DMA pipeline)
+        o1, o2 = eng.linear(a, w, b), eng.linear(a, w, b)
+        assert torch.equal(o1, o2)
+    finally:
+        eng.set_option("gemm_mode", 1)
+
+
+def test_gemm256_equals_gemm128_bitwise_per_element_order(eng):
+    """Both kernels accumulate every output over k in the same MFMA order -> identical fp16 results."""
+    g = torch.Generator().manual_seed(99)
+    a = (torch.randn(700, 1280, generator=g) * 0.5).half()
+    w = (torch.randn(1280, 1280, generator=g) * 0.05).half()
+    eng.set_option("gemm_mode", 0)
+    o128 = eng.linear(a, w, None)
+    eng.set_option("gemm_mode", 2)
+    o256 = eng.linear(a, w, None)
+    eng.set_option("gemm_mode", 1)
+    assert torch.equal(o128, o256)

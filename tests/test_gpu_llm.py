@@ -195,3 +195,25 @@ def test_reference_operator_seam_matches_engine_path():
             m.llm.generate(**out, do_sample=False, num_beams=4, max_new_tokens=4)
     finally:
         eng.close()
+
+
+def test_prefill_gemm256_equals_gemm128():
+    """Llama prefill through the 256x256 kernel (RoPE + paged-KV epilogue) reproduces the 128x128 path's tokens/logits."""
+    cfg = LLM_CFGS["hd128"]
+    emb = torch.randn(300, cfg["hidden_size"], generator=torch.Generator().manual_seed(13)).half().float()
+    eng, w = make_engine(cfg, 6, max_batch=1, use_graph=False)
+    try:
+        res = []
+        for mode in (0, 2):
+            eng.set_option("gemm_mode", mode)
+            eng.begin_batch(1, 8, None)
+            eng.prefill(0, padded(emb), 300)
+            lg = eng.logits().clone()
+            eng.decode(7)
+            res.append((lg, eng.outputs()[0]))
+        eng.set_option("gemm_mode", 1)
+        assert torch.equal(res[0][0], res[1][0])
+        assert res[0][1] == res[1][1]
+    finally:
+        eng.set_option("gemm_mode", 1)
+        eng.close()

@@ -115,3 +115,25 @@ def test_vit_encode_double_run_bitwise():
         assert torch.equal(a, b)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_hd16", "hd80_gelu", "mid_t730"])
+def test_vit_layer_gemm256_equals_gemm128(name):
+    """The 256x256 kernel's QKV-fragment / V^T epilogues give the same layer output as the 128x128 kernel's."""
+    cfg, frames, r = CFGS[name]
+    eng, w = make_engine(cfg, frames, 46)
+    try:
+        t = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+        x = torch.randn(frames, t, cfg["hidden_size"], generator=torch.Generator().manual_seed(3)).half()
+        outs = []
+        for mode in (0, 2):
+            eng.set_option("gemm_mode", mode)
+            xo, so, metric, idx = eng.vit_layer(0, x, None, r)
+            outs.append((xo.clone(), metric.clone(), idx["src_idx"].clone()))
+        eng.set_option("gemm_mode", 1)
+        assert torch.equal(outs[0][1], outs[1][1])          # K fragments -> metric
+        assert torch.equal(outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0])
+    finally:
+        eng.set_option("gemm_mode", 1)
+        eng.close()

@@ -78,7 +78,11 @@ def main():
                 run(f"attn v{variant} pps{pps}", ["dec_attn"])
     else:
         run("attn v1 pps4", ["dec_attn"])
-    run("prefill", ["pre_norm", "pre_qkv", "pre_attn", "pre_o", "pre_gateup", "pre_down"])
+    for mode, tag in ((0, "prefill gemm128"), (2, "prefill gemm256")):
+        eng.set_option("gemm_mode", mode)
+        run(tag, ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
+    eng.set_option("gemm_mode", 1)
+    run("prefill", ["pre_norm", "pre_attn"])
     print(json.dumps(res))
     eng.close()
 
