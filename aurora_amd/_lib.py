@@ -56,6 +56,7 @@ SIGNATURES = {
     "aur_project_splice": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "aur_begin_batch": (C.c_int, [_P, _I, _I, _I, _P]),
     "aur_llm_prefill": (C.c_int, [_P, _I, _P, _I, _P]),
+    "aur_llm_prefill_batch": (C.c_int, [_P, _I, _I, _P, _I, _P]),
     "aur_llm_decode": (C.c_int, [_P, _I, _P]),
     "aur_get_outputs": (C.c_int, [_P, _IP, _IP, _P]),
     "aur_unfinished": (C.c_int, [_P, _IP, _P]),

@@ -67,7 +67,7 @@ struct aur_ctx {
     int32_t *s_pos, *s_ids, *s_len, *s_fin, *s_ptab;
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
-    int fuse_norm = 0, attn_variant = 1, row_waves = 8, last_prefill_len = 0;      // tuning knobs (aur_set_option)
+    int fuse_norm = 0, attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     // profiling
@@ -187,7 +187,8 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->w_sza = k.take<float>(F * TP);
     c->w_szb = k.take<float>(F * TP);
     // llm
-    const int64_t LP = c->l_ctx_pad, d = g.llm_hidden, B = g.max_batch;
+    const int64_t B = g.max_batch, d = g.llm_hidden;
+    const int64_t LP = (int64_t)c->l_ctx_pad * B;          // batched prefill: up to max_batch sequences in one pass
     c->l_xn = k.take<half_t>(LP * d);
     c->l_qf = k.take<half_t>(LP * d);
     c->l_attn = k.take<half_t>(LP * d);
@@ -717,21 +718,21 @@ static int lm_head_and_advance(aur_ctx* ctx, const half_t* xn, int b0, int nb, i
 
 // One prefill layer; `which` selects the kernels (bit 0 norm1, 1 qkv, 2 attention, 3 o_proj, 4 norm2, 5 gate/up, 6 down)
 // so that aur_microbench can time each of them in isolation.
-static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, half_t* x, int seq_len, hipStream_t s) {
+static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, half_t* x, int seq_len, hipStream_t s) {
     const aur_config& g = ctx->cfg;
     const LlmLayerW& w = ctx->ll[l];
-    const int d = g.llm_hidden, M = rup(seq_len, 32);
+    const int d = g.llm_hidden, Mseq = rup(seq_len, 32), M = nseq * Mseq;
     if (which & 1) CK(launch_rmsnorm(x, d, w.ln1_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
     if (which & 2) {
         GemmArgs q{};
         q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
-        q.rows_per_seq = M; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
+        q.rows_per_seq = Mseq; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
         q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot;
         CK(launch_gemm(q, EPI_QKV, s));
     }
     if (which & 4) {
         AttnArgs at{};
-        at.Qf = ctx->l_qf; at.kv = llm_kv(ctx, l); at.seq0 = slot; at.nseq = 1; at.heads = g.llm_heads; at.rows_per_seq = M; at.t = seq_len;
+        at.Qf = ctx->l_qf; at.kv = llm_kv(ctx, l); at.seq0 = slot; at.nseq = nseq; at.heads = g.llm_heads; at.rows_per_seq = Mseq; at.t = seq_len;
         at.causal = 1; at.scale = 1.0f / sqrtf((float)ctx->l_hd); at.O = ctx->l_attn; at.ldo = d; at.hd = ctx->l_hd;
         CK(launch_attention(at, s));
     }
@@ -757,27 +758,30 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, half_t* x, in
     return AUR_OK;
 }
 
-extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
+extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
     if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_prefill: language weights not finalized");
     const aur_config& g = ctx->cfg;
-    if (slot < 0 || slot >= ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "slot %d outside the batch of %d (aur_begin_batch)", slot, ctx->batch);
+    if (nseq < 1 || slot0 < 0 || slot0 + nseq > ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "slots [%d, %d) outside the batch of %d (aur_begin_batch)", slot0, slot0 + nseq, ctx->batch);
     if (seq_len < 1 || seq_len + ctx->max_new > g.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, g.max_ctx);
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "prefill", s);
-    const int d = g.llm_hidden;
+    const int d = g.llm_hidden, Mseq = rup(seq_len, 32);
     half_t* x = (half_t*)embeds;
     ctx->last_prefill_len = seq_len;
     for (int l = 0; l < g.llm_layers; ++l) {
-        int rc = prefill_layer(ctx, l, 0x7f, slot, x, seq_len, s);
+        int rc = prefill_layer(ctx, l, 0x7f, slot0, nseq, x, seq_len, s);
         if (rc) return rc;
     }
-    // logits of the last prompt position -> first generated token
-    half_t* xn1 = ctx->d_xn + (int64_t)slot * d;
-    CK(launch_rmsnorm(x + (int64_t)(seq_len - 1) * d, d, ctx->l_norm_w, g.llm_rms_eps, 1, d, xn1, d, s));
-    int rc = lm_head_and_advance(ctx, xn1, slot, 1, 0, seq_len, s);
+    // logits of each sequence's last prompt position -> first generated tokens
+    half_t* xn1 = ctx->d_xn + (int64_t)slot0 * d;
+    CK(launch_rmsnorm(x + (int64_t)(seq_len - 1) * d, Mseq * d, ctx->l_norm_w, g.llm_rms_eps, nseq, d, xn1, d, s));
+    int rc = lm_head_and_advance(ctx, xn1, slot0, nseq, 0, seq_len, s);
     if (rc) return rc;
     stage_end(ctx, "prefill", s);
     return AUR_OK;
+}
+extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
+    return aur_llm_prefill_batch(ctx, slot, 1, embeds, seq_len, stream);
 }
 
 // ---- decode-step kernel argument builders (shared by the step and by aur_microbench)
@@ -919,6 +923,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
+    else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
@@ -961,7 +966,7 @@ extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, d
                       : !strcmp(kernel, "pre_gateup") ? 32 : !strcmp(kernel, "pre_down") ? 64 : 0;
             if (!bit) return aur_fail(ctx, AUR_ERR_ARG, "unknown kernel '%s'", kernel);
             // scratch residual stream: l_p1 (projector scratch) is free after the splice
-            return prefill_layer(ctx, l, bit, 0, ctx->l_p1, ctx->last_prefill_len, s);
+            return prefill_layer(ctx, l, bit, 0, ctx->mb_nseq, ctx->l_p1, ctx->last_prefill_len, s);
         }
         return AUR_OK;
     };

@@ -263,7 +263,7 @@ class AuroraCapEngine:
         assert nk.value == n_kept
         return out
 
-    def project_splice(self, vis: torch.Tensor, input_ids: Sequence[int]):
+    def project_splice(self, vis: torch.Tensor, input_ids: Sequence[int], out: Optional[torch.Tensor] = None):
         """vis [frames, n_kept, Dv] + ids (with -200 markers) -> (embeds [L_pad, d] fp16, seq_len).
 
         Host builds the destination-row maps (model/utils.py:198-240 semantics: marker k takes frame k;
@@ -289,11 +289,12 @@ class AuroraCapEngine:
         vr_t = torch.from_numpy(vr.astype(np.int32)).to(self.dev)
         ti_t = torch.tensor(text_ids, dtype=torch.int32, device=self.dev)
         tr_t = torch.tensor(text_rows, dtype=torch.int32, device=self.dev)
-        embeds = torch.empty(_rup(seq_len, 32), d, dtype=torch.float16, device=self.dev)
+        embeds = out if out is not None else torch.empty(_rup(seq_len, 32), d, dtype=torch.float16, device=self.dev)
+        assert embeds.shape[0] >= _rup(seq_len, 32) and embeds.is_contiguous()
         check(self.ctx, self.L.aur_project_splice(self.ctx, vflat.data_ptr(), vflat.shape[0], vr_t.data_ptr(), ti_t.data_ptr(),
                                                   tr_t.data_ptr(), len(text_ids), seq_len, embeds.data_ptr(), self._stream()),
               "aur_project_splice")
-        self._tmp = (vflat, vr_t, ti_t, tr_t)      # keep alive until the stream has consumed them
+        self._tmp = getattr(self, "_tmp", [])[-64:] + [(vflat, vr_t, ti_t, tr_t)]      # keep alive until consumed
         return embeds, seq_len
 
     def begin_batch(self, batch: int, max_new_tokens: int, eos_id: Optional[int]):
@@ -303,6 +304,11 @@ class AuroraCapEngine:
 
     def prefill(self, slot: int, embeds: torch.Tensor, seq_len: int):
         check(self.ctx, self.L.aur_llm_prefill(self.ctx, slot, embeds.data_ptr(), seq_len, self._stream()), "aur_llm_prefill")
+
+    def prefill_batch(self, slot0: int, nseq: int, embeds: torch.Tensor, seq_len: int):
+        """embeds [nseq * round_up(seq_len, 32), d]: equal-length sequences prefetched in ONE pass (large-M GEMMs)."""
+        check(self.ctx, self.L.aur_llm_prefill_batch(self.ctx, slot0, nseq, embeds.data_ptr(), seq_len, self._stream()),
+              "aur_llm_prefill_batch")
 
     def decode(self, steps: int):
         check(self.ctx, self.L.aur_llm_decode(self.ctx, steps, self._stream()), "aur_llm_decode")

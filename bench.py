@@ -33,6 +33,7 @@ def parse():
     p.add_argument("--num_frm", type=int, default=8)
     p.add_argument("--token_kept_ratio", type=float, default=0.3)
     p.add_argument("--max_new_tokens", type=int, default=256)
+    p.add_argument("--prefill-group", type=int, default=4, help="clips prefetched per prefill pass (equal-length prompts)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
@@ -133,6 +134,7 @@ def main():
     ids = [S.prompt_ids(F, clip0 + b, 30, l["vocab_size"]) for b in range(B)]
     torch.cuda.synchronize()
 
+    emb_all = torch.zeros(max(1, min(args.prefill_group, B)) * _rup(L0, 32), l["hidden_size"], dtype=torch.float16, device=dev)
     ttft_ms = []
 
     def step(record_ttft=False):
@@ -141,13 +143,18 @@ def main():
         vis = eng.vit_encode(pixels, r)                            # [B*F, n_kept, Dv]
         eng.begin_batch(B, N, None)
         evs = []
-        for b in range(B):
-            emb, L = eng.project_splice(vis[b * F:(b + 1) * F], ids[b])
-            eng.prefill(b, emb, L)
+        G = max(1, min(args.prefill_group, B))
+        Mseq = _rup(L0, 32)
+        for b0 in range(0, B, G):                                  # equal-length prompts: G clips per prefill pass
+            n = min(G, B - b0)
+            for j in range(n):
+                _, L = eng.project_splice(vis[(b0 + j) * F:(b0 + j + 1) * F], ids[b0 + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+                assert L == L0
+            eng.prefill_batch(b0, n, emb_all, L0)
             if record_ttft:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
-                evs.append(e)
+                evs.extend([e] * n)
         eng.decode(N - 1)
         out = eng.outputs()                                        # synchronises
         if world > 1:                                              # result gather over RCCL / xGMI
@@ -189,7 +196,7 @@ def main():
                                     % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
                        "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
                        "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
-                       "decode": "hipGraph" if not args.no_graph else "eager"},
+                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": max(1, min(args.prefill_group, B))},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "ttft_note": "time from step start to each clip's first token inside a batch of %d clips (ViT for all clips runs first)" % B,
         }

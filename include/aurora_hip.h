@@ -106,6 +106,9 @@ int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t
 /* Prefill `slot` with embeds [round_up(seq_len,32), llm_hidden] (clobbered), write its KV pages, produce the
  * first token (argmax of the last position's logits). */
 int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream);
+/* Same for `nseq` sequences of EQUAL length in slots [slot0, slot0 + nseq): embeds is
+ * [nseq * round_up(seq_len,32), llm_hidden]; one pass of M = nseq * round_up(seq_len,32) rows through every GEMM. */
+int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream);
 /* Run `steps` decode steps for slots [0, batch): one new token per unfinished slot per step. */
 int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream);
 /* Synchronises the stream and copies results to host: ids [batch * max_new_tokens], lens [batch]. */
