@@ -4,278 +4,352 @@
 // Reference: third-party transformers LlamaForCausalLM.generate greedy loop as called at
 // inference.py:89-96 (one position per step with a KV cache, argmax, EOS / max_new_tokens stop).
 //
-// skinny GEMM   y[b, n] = sum_k x[b, k] W[n, k]   for b <= 16 rows:
-//   Weights are the same FRAG tiles the prefill GEMM uses ([N/16][K/32][64][8]); a wave streams one
-//   1 KiB fragment per global_load_dwordx4 straight into VGPRs (no LDS round trip for a once-read
-//   operand), x (<= 16 x K halves) is staged once per workgroup into LDS and read back as the MFMA B
-//   operand; one 16x16x32 MFMA per KiB of weights keeps the VALU idle and the loop purely HBM-bound.
-//   A workgroup owns NT n16 tiles over the full K; its 4 waves split K interleaved (wave w takes
-//   k32 = 4i + w, so the 4 waves walk 4 consecutive KiB), reduced through LDS in fixed order.
+// skinny GEMM   y[b, n] = sum_k x[b, k] W[n, k]   for b <= 32 rows:
+//   * Weights are the same FRAG tiles the prefill GEMM uses ([N/16][K/32][64][8]); a wave streams one
+//     1 KiB fragment per global_load_dwordx4 (non-temporal) straight into VGPRs - no LDS round trip for a
+//     once-read operand.
+//   * Activations travel BETWEEN decode kernels in "x-fragment" form, [ceil(B/16)][K/32][64 lanes][8] with
+//     lane = g*16 + (b % 16): exactly the MFMA B operand.  A wave reads the fragment it needs with one 16-byte
+//     load per lane (L2-resident: B x K halves <= 700 KiB), so there is no per-workgroup LDS staging, no K
+//     chunking and no barrier inside the stream loop; producers (RMSNorm, attention combine, the SiLU*up
+//     epilogue) write this layout directly.
+//   * One 16x16x32 MFMA per KiB of weights (x 2 column groups when B > 16) keeps the VALU idle: the loop is
+//     purely HBM-bound.  A workgroup owns NT n16 tiles over the full K; its NW waves split K interleaved
+//     (wave w takes k32 = w + NW*i, so the waves walk consecutive KiB), reduced through LDS in fixed order
+//     (deterministic, batch-invariant).
+//
+//   * No RMSNorm kernels in the decode step: the norm WEIGHTS are folded into the consuming projection at pack time
+//     (W' = W diag(w_norm)), the residual stream lives in x-fragment form, the residual-producing epilogues (o / down
+//     projection, next-token embedding) accumulate sum(x^2) per row as 2^-28 fixed point with 64-bit integer atomics
+//     (integer addition commutes: bitwise deterministic and batch-invariant), and the consumer scales its accumulators
+//     by rstd[b] = rsqrt(sum/K + eps).
 //
 // decode attention: one wave per (sequence, head, split of 64-token pages).  K fragments (rows = tokens)
 //   and V^T fragments (rows = d) stream from the paged cache as contiguous 1 KiB pieces; q is replicated
 //   across the 16 MFMA columns.  S^T accumulators become the PAIRED-token P operand in-lane.
 #include "kernels.h"
 
-#define SK_LDS_BUDGET (72 * 1024)
+// address (halves) of the 16-byte piece holding x[b][k .. k+8) (k % 8 == 0) in x-fragment form
+__device__ __forceinline__ int64_t xfrag_piece(int b, int k, int K32) {
+    return ((((int64_t)(b >> 4) * K32 + (k >> 5)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8;
+}
 
-template <int NT, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a, int KC) {
+#define SSQ_SCALE 268435456.0f      /* 2^28 */
+__device__ __forceinline__ float ssq_to_rstd(unsigned long long s, int k, float eps) {
+    return rsqrtf((float)((double)s * (1.0 / 268435456.0)) / (float)k + eps);
+}
+
+template <int NT, int MODE, int NW, int NB>
+__global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
+    if (a.ssq_zero && blockIdx.x == 0 && tid < 32) a.ssq_zero[tid] = 0ull;     // reset the accumulator a LATER kernel fills
     const int K32 = a.K >> 5;
     const int tile0 = blockIdx.x * NT;
-    half_t* xs = (half_t*)smem;
-    const int xrow = (c < a.B) ? c : c % a.B;
 
-    f4 acc[NT];
+    f4 acc[NT][NB];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // The weight stream is ONE continuous software pipeline over all of this wave's k32 tiles (wave w owns
-    // tiles w, w+4, ...): the first batch is in flight before x is staged, and it keeps running across the
-    // x-chunk boundaries (chunks exist only because B x K halves may exceed the LDS budget).
+    // ONE continuous software pipeline over this wave's k32 tiles: U tiles of W (and x) fragments in registers,
+    // the next U in flight.
     constexpr int U = 4;
-    const int nit = a.K / (32 * NW);             // tiles per wave (wave w owns tiles w, w+NW, ...)
-    const int tpc = KC / (32 * NW);              // tiles per wave per x-chunk (multiple of U when there are several chunks)
-    const int ldxs = KC + 8;
+    const int nit = a.K / (32 * NW);
     const half_t* wp[NT];
+    const half_t* xp[NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wp[t] = a.W + ((int64_t)(tile0 + t) * K32 + w) * AUR_FRAG_HALVES + lane * 8;
-    const half_t* xp = xs + xrow * ldxs + w * 32 + g * 8;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xp[nb] = a.xf + ((int64_t)nb * K32 + w) * AUR_FRAG_HALVES + lane * 8;
+    constexpr int64_t STEP = (int64_t)NW * AUR_FRAG_HALVES;
     const int nfull = nit / U * U;
-    h8 cur[U][NT], nxt[U][NT];
+    h8 cw[U][NT], cx[U][NB], nw[U][NT], nx[U][NB];
     if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cw[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + u * STEP));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) cx[u][nb] = *(const h8*)(xp[nb] + u * STEP);
+        }
+    }
+    int i0 = 0;
+    for (; i0 < nfull; i0 += U) {
+        const bool more = (i0 + 2 * U <= nfull);            // wave-uniform: one branch per batch
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) nw[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (i0 + U + u) * STEP));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) nx[u][nb] = *(const h8*)(xp[nb] + (i0 + U + u) * STEP);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                cur[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)u * NW * AUR_FRAG_HALVES));
-    }
-    // Fused RMSNorm (HF LlamaRMSNorm) at zero extra passes: y = rstd[b] * sum_k W[n,k] * (w_norm[k] * x[b,k]).
-    // The staging pass multiplies by w_norm and accumulates sum(x^2) per row on the fly; rstd[b] scales the
-    // accumulators in the epilogue.  Row b is staged and summed by wave (b mod NW) alone: lane partials over pieces
-    // lane, lane+64, ... in chunk order, then a fixed butterfly - the same arithmetic for any batch size.
-    const size_t x_bytes = (size_t)a.B * ldxs * 2, red_bytes = (size_t)NW * NT * 64 * 16;
-    float* rs = (float*)(smem + (x_bytes > red_bytes ? x_bytes : red_bytes));   // [16] sum(x^2) per row
-    auto stage = [&](int chunk) {               // block-uniform: every wave calls it at the same tile index
-        __syncthreads();
-        const int kc0 = chunk * KC;
-        const int kc = (a.K - kc0) < KC ? (a.K - kc0) : KC;
-        const int ppr = kc >> 3;
-        if (a.norm_w) {
 #pragma unroll
-            for (int rr = 0; rr < 16 / NW; ++rr) {
-                const int b = w + rr * NW;               // wave-uniform
-                if (b < a.B) {
-                    float ss = 0.f;
-                    for (int p = lane; p < ppr; p += 64) {
-                        h8 v = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
-                        const float* nw = a.norm_w + kc0 + p * 8;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float xv = (float)v[e];
-                            ss += xv * xv;
-                            v[e] = (half_t)(nw[e] * xv);
-                        }
-                        *(h8*)(xs + b * ldxs + p * 8) = v;
-                    }
-                    ss = wave_sum(ss);
-                    if (lane == 0) rs[b] = (chunk == 0 ? 0.f : rs[b]) + ss;
-                }
-            }
-        } else {
-            for (int idx = tid; idx < a.B * ppr; idx += 64 * NW) {
-                const int b = idx / ppr, p = idx % ppr;
-                *(h8*)(xs + b * ldxs + p * 8) = *(const h8*)(a.x + (int64_t)b * a.ldx + kc0 + p * 8);
-            }
-        }
-        __syncthreads();
-    };
-    int staged = -1;
-    int i0 = 0;
-    for (; i0 < nfull; i0 += U) {
-        const int chunk = i0 / tpc;
-        if (chunk != staged) {
-            stage(chunk);
-            staged = chunk;
-        }
-        const bool more = (i0 + 2 * U <= nfull);            // wave-uniform: one branch per batch
+                for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(cw[u][t], cx[u][nb], acc[t][nb]);
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    nxt[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)(i0 + U + u) * NW * AUR_FRAG_HALVES));
-        }
-        const int il = i0 - chunk * tpc;
+                for (int t = 0; t < NT; ++t) cw[u][t] = nw[u][t];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const h8 xf = *(const h8*)(xp + (il + u) * (32 * NW));
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[u][t], xf, acc[t]);
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) cur[u][t] = nxt[u][t];
+                for (int nb = 0; nb < NB; ++nb) cx[u][nb] = nx[u][nb];
+            }
         }
     }
     for (; i0 < nit; ++i0) {                     // tail (< U tiles)
-        const int chunk = i0 / tpc;
-        if (chunk != staged) {
-            stage(chunk);
-            staged = chunk;
-        }
-        const h8 xf = *(const h8*)(xp + (i0 - chunk * tpc) * (32 * NW));
+        h8 xf[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) xf[nb] = *(const h8*)(xp[nb] + i0 * STEP);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const h8 wf = __builtin_nontemporal_load((const h8*)(wp[t] + (int64_t)i0 * NW * AUR_FRAG_HALVES));
-            acc[t] = mfma16(wf, xf, acc[t]);
+            const h8 wf = __builtin_nontemporal_load((const h8*)(wp[t] + i0 * STEP));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(wf, xf[nb], acc[t][nb]);
         }
     }
     // cross-wave reduction in fixed order
-    __syncthreads();
-    float* red = (float*)smem;       // [NW waves][NT][64 lanes][4]
+    float* red = (float*)smem;       // [NW waves][NT*NB][64 lanes][4]
 #pragma unroll
-    for (int t = 0; t < NT; ++t) *(f4*)(red + ((w * NT + t) * 64 + lane) * 4) = acc[t];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(red + (((w * NT + t) * NB + nb) * 64 + lane) * 4) = acc[t][nb];
     __syncthreads();
     if (w != 0) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f4 s = *(const f4*)(red + ((0 * NT + t) * 64 + lane) * 4);
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) {
-            const f4 p = *(const f4*)(red + ((ww * NT + t) * 64 + lane) * 4);
+        for (int nb = 0; nb < NB; ++nb) {
+            f4 s = *(const f4*)(red + (((0 * NT + t) * NB + nb) * 64 + lane) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] += p[i];
+            for (int ww = 1; ww < NW; ++ww) {
+                const f4 p = *(const f4*)(red + (((ww * NT + t) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += p[i];
+            }
+            acc[t][nb] = s;
         }
-        acc[t] = s;
-    }
-    const int b = c;
-    if (b >= a.B) return;
-    if (a.norm_w) {                                   // fused RMSNorm: per-row 1/rms applied to the contraction
-        const float rstd = rsqrtf(rs[b] / (float)a.K + a.norm_eps);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][i] *= rstd;
-    }
 
-    if (MODE == SK_ROW || MODE == SK_LOGITS || MODE == SK_SILU_MUL) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = (tile0 + t) * 16 + 4 * g;
-            if (n >= a.n_real) continue;
-            if (MODE == SK_LOGITS) {
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = nb * 16 + c;
+        if (b < a.b_lo || b >= a.b_hi) continue;
+        if (a.ssq_in) {                                   // folded RMSNorm: per-row 1/rms of the (un-normalised) input
+            const float rstd = ssq_to_rstd(a.ssq_in[b], a.K, a.norm_eps);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a.out32[(int64_t)b * a.n_real + n + i] = acc[t][i];
-            } else if (MODE == SK_SILU_MUL) {
-                h2 o;
-                o[0] = (half_t)(silu_f(acc[t][0]) * acc[t][1]);
-                o[1] = (half_t)(silu_f(acc[t][2]) * acc[t][3]);
-                *(h2*)(a.out + (int64_t)b * a.ldo + (n >> 1)) = o;
-            } else {
-                float v[4];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[t][i];
-                if (a.resid) {
-                    const h4 rr = *(const h4*)(a.resid + (int64_t)b * a.ldr + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
-                }
-                h4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
-                *(h4*)(a.out + (int64_t)b * a.ldo + n) = o;
-            }
+                for (int i = 0; i < 4; ++i) acc[t][nb][i] *= rstd;
         }
-    } else if (NT == 2) {     // SK_QKV: the workgroup owns one PAIRED 32-column block
-        const KvLayout& kv = a.kv;
-        const int nb = tile0 * 16;
-        const int pos = a.pos[b];
-        const int seq = a.seq_ids ? a.seq_ids[b] : b;
-        half_t* page = kv_page(kv, seq, pos);
-        if (nb < a.q_cols + a.k_cols) {
-            const bool is_q = nb < a.q_cols;
-            const int nreg = is_q ? nb : nb - a.q_cols;
-            const int blkg = nreg >> 5;
-            const int head = blkg / kv.kblk, blk = blkg % kv.kblk;
-            if (head >= kv.heads) return;
-            const float2* cs = a.rope + (int64_t)pos * (a.hd >> 1) + blk * 16 + 4 * g;
-            h8 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float2 cc = cs[i];
-                const float x1 = acc[0][i], x2 = acc[NT - 1][i];
-                o[i] = (half_t)(x1 * cc.x - x2 * cc.y);
-                o[4 + i] = (half_t)(x2 * cc.x + x1 * cc.y);
-            }
-            if (is_q) *(h8*)(a.qbuf + ((((int64_t)b * kv.heads + head) * kv.kblk + blk) * 4 + g) * 8) = o;
-            else *(h8*)(page + kfrag_off(kv, head, (pos % kv.page_tokens) >> 4, blk) + (g * 16 + (pos & 15)) * 8) = o;
-        } else {
-            const int nreg = nb - a.q_cols - a.k_cols;
-            const int tp = pos & 31;
-            const int gt = (tp & 15) >> 2, jt = (tp & 3) + ((tp >> 4) << 2);
+        if (MODE == SK_ROW || MODE == SK_LOGITS || MODE == SK_SILU_MUL) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int idx = (nreg >> 4) + t;
-                const int head = idx / kv.vd16, d16 = idx % kv.vd16;
-                if (head >= kv.heads) continue;
-                half_t* fr = page + vfrag_off(kv, head, d16, (pos % kv.page_tokens) >> 5);
+                const int tile = tile0 + t;
+                const int n = tile * 16 + 4 * g;
+                if (n >= a.n_real) continue;
+                if (MODE == SK_LOGITS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fr[(gt * 16 + 4 * g + i) * 8 + jt] = (half_t)acc[t][i];
+                    for (int i = 0; i < 4; ++i) a.out32[(int64_t)b * a.n_real + n + i] = acc[t][nb][i];
+                } else if (MODE == SK_SILU_MUL) {
+                    // h[b][k], k = n/2 + {0,1} = tile*8 + 2g + {0,1}, written in x-fragment form for the down projection
+                    h2 o;
+                    o[0] = (half_t)(silu_f(acc[t][nb][0]) * acc[t][nb][1]);
+                    o[1] = (half_t)(silu_f(acc[t][nb][2]) * acc[t][nb][3]);
+                    half_t* dst = a.out_f + ((((int64_t)(b >> 4) * a.out_k32 + (tile >> 2)) * 64) + (tile & 3) * 16 + (b & 15)) * 8 + 2 * g;
+                    *(h2*)dst = o;
+                } else {
+                    // residual update in place, in x-fragment form: x[b][n..n+3] += y; and sum(x_new^2) for the next norm
+                    half_t* px = a.xres + xfrag_piece(b, n & ~7, a.n_real >> 5) + (n & 7);
+                    const h4 rr = *(const h4*)px;
+                    h4 o;
+                    float p = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o[i] = (half_t)(acc[t][nb][i] + (float)rr[i]);
+                        p += (float)o[i] * (float)o[i];
+                    }
+                    *(h4*)px = o;
+                    p += __shfl_xor(p, 16, 64);
+                    p += __shfl_xor(p, 32, 64);
+                    if (g == 0 && a.ssq_out) atomicAdd(a.ssq_out + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
+                }
+            }
+        } else if (NT == 2) {     // SK_QKV: the workgroup owns one PAIRED 32-column block
+            const KvLayout& kv = a.kv;
+            const int nbc = tile0 * 16;
+            const int pos = a.pos[b];
+            const int seq = a.seq_ids ? a.seq_ids[b] : b;
+            half_t* page = kv_page(kv, seq, pos);
+            if (nbc < a.q_cols + a.k_cols) {
+                const bool is_q = nbc < a.q_cols;
+                const int nreg = is_q ? nbc : nbc - a.q_cols;
+                const int blkg = nreg >> 5;
+                const int head = blkg / kv.kblk, blk = blkg % kv.kblk;
+                if (head >= kv.heads) continue;
+                const float2* cs = a.rope + (int64_t)pos * (a.hd >> 1) + blk * 16 + 4 * g;
+                h8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 cc = cs[i];
+                    const float x1 = acc[0][nb][i], x2 = acc[NT - 1][nb][i];
+                    o[i] = (half_t)(x1 * cc.x - x2 * cc.y);
+                    o[4 + i] = (half_t)(x2 * cc.x + x1 * cc.y);
+                }
+                if (is_q) *(h8*)(a.qbuf + ((((int64_t)b * kv.heads + head) * kv.kblk + blk) * 4 + g) * 8) = o;
+                else *(h8*)(page + kfrag_off(kv, head, (pos % kv.page_tokens) >> 4, blk) + (g * 16 + (pos & 15)) * 8) = o;
+            } else {
+                const int nreg = nbc - a.q_cols - a.k_cols;
+                const int tp = pos & 31;
+                const int gt = (tp & 15) >> 2, jt = (tp & 3) + ((tp >> 4) << 2);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int idx = (nreg >> 4) + t;
+                    const int head = idx / kv.vd16, d16 = idx % kv.vd16;
+                    if (head >= kv.heads) continue;
+                    half_t* fr = page + vfrag_off(kv, head, d16, (pos % kv.page_tokens) >> 5);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fr[(gt * 16 + 4 * g + i) * 8 + jt] = (half_t)acc[t][nb][i];
+                }
             }
         }
     }
 }
 
-template <int NT, int MODE, int NW>
+template <int NT, int MODE, int NW, int NB>
 static hipError_t launch_skinny_t(const SkinnyArgs& a, hipStream_t s) {
-    // chunk K so that B x (KC + 8) halves fit the LDS budget; chunk boundaries fall on whole U-tile batches
-    constexpr int G = 32 * NW * 4;
-    int kc = a.K;
-    const int maxk = (SK_LDS_BUDGET / (2 * a.B) - 8) / G * G;
-    if (kc > maxk) {
-        const int nch = (a.K + maxk - 1) / maxk;
-        kc = (((a.K + nch - 1) / nch) + G - 1) / G * G;
-    }
-    size_t lds = (size_t)a.B * (kc + 8) * 2;                // x image
-    const size_t red = (size_t)NW * NT * 64 * 16;
-    if (lds < red) lds = red;
-    lds += 64;                                              // 16 row sums (fused RMSNorm), after both regions
-    hipLaunchKernelGGL((skinny_kernel<NT, MODE, NW>), dim3(a.Npad / (16 * NT)), dim3(64 * NW), lds, s, a, kc);
+    const size_t lds = (size_t)NW * NT * NB * 64 * 16;
+    hipLaunchKernelGGL((skinny_kernel<NT, MODE, NW, NB>), dim3(a.Npad / (16 * NT)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NT, int MODE, int NW>
-static hipError_t skinny_attr() {
-    return hipFuncSetAttribute((const void*)skinny_kernel<NT, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-}
-hipError_t skinny_init() {
-    hipError_t e;
-    if ((e = skinny_attr<1, SK_ROW, 4>()) != hipSuccess) return e;
-    if ((e = skinny_attr<1, SK_ROW, 8>()) != hipSuccess) return e;
-    if ((e = skinny_attr<1, SK_LOGITS, 4>()) != hipSuccess) return e;
-    if ((e = skinny_attr<2, SK_SILU_MUL, 4>()) != hipSuccess) return e;
-    return skinny_attr<2, SK_QKV, 4>();
-}
+hipError_t skinny_init() { return hipSuccess; }      // <= 32 KiB of LDS: no attribute needed
 
-hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    if (a.B < 1 || a.B > 16 || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
+template <int NB>
+static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
     switch (a.mode) {
         case SK_ROW:
             // few output tiles (N = hidden): 8 waves per workgroup double the loads in flight per CU
-            if (a.waves == 8 && (a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8>(a, s);
-            return launch_skinny_t<1, SK_ROW, 4>(a, s);
-        case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS, 4>(a, s);
-        case SK_SILU_MUL: return launch_skinny_t<2, SK_SILU_MUL, 4>(a, s);
-        case SK_QKV: return launch_skinny_t<2, SK_QKV, 4>(a, s);
+            if (a.waves == 8 && (a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8, NB>(a, s);
+            return launch_skinny_t<1, SK_ROW, 4, NB>(a, s);
+        case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS, 4, NB>(a, s);
+        case SK_SILU_MUL: return launch_skinny_t<2, SK_SILU_MUL, 4, NB>(a, s);
+        case SK_QKV: return launch_skinny_t<2, SK_QKV, 4, NB>(a, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
+    if (a.B < 1 || a.B > 32 || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
+    return a.B > 16 ? launch_skinny_nb<2>(a, s) : launch_skinny_nb<1>(a, s);
+}
+
+// ------------------------------------------------------------------------------------ x-fragment producers
+// xf[b0 + row] = (RMSNorm(x[row]) if w else x[row]) in x-fragment form.  One wave per row.
+// One 1024-thread workgroup per group of 16 batch rows (rows b0 .. b0+rows-1 all lie in groups starting at b0 & ~15):
+//   phase 1: wave r computes sum(x^2) of row r (one wave per row, fixed butterfly order)           -> rstd[r] in LDS
+//   phase 2: wave w builds k32 tiles w, w+16, ...: lane (g, r) reads x[r][k32*32 + g*8 .. +8], normalises, and the
+//            64 lanes store one complete 1 KiB fragment (fully coalesced; rows outside [b0, b0+rows) keep zeros).
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void xfrag_norm_kernel(const half_t* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                          float eps, int rows, int d, int b0, half_t* __restrict__ xf,
+                                                          unsigned long long* __restrict__ ssq_out) {
+    __shared__ float rs[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = (b0 >> 4) + blockIdx.x;                 // 16-row group handled by this workgroup
+    const int K32 = d >> 5;
+    for (int rr = wv; rr < 16; rr += NWV) {                 // phase 1: wave wv <-> rows wv, wv + NWV, ... of the group
+        const int b = grp * 16 + rr;
+        const int row = b - b0;
+        float ss = 0.f;
+        if (row >= 0 && row < rows && (w || ssq_out)) {
+            const half_t* xr = x + row * ldx;
+            const int nchunk = d >> 3;
+            for (int c0 = 0; c0 < nchunk; c0 += 512) {          // batches of 8 independent 16-byte loads per lane
+                h8 t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int cch = c0 + lane + i * 64;
+                    if (cch < nchunk) t[i] = *(const h8*)(xr + cch * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int cch = c0 + lane + i * 64;
+                    if (cch < nchunk) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss += (float)t[i][j] * (float)t[i][j];
+                    }
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            rs[rr] = w ? rsqrtf(ss / (float)d + eps) : 1.f;
+            if (ssq_out && row >= 0 && row < rows) ssq_out[b] = (unsigned long long)__float2ll_rn(ss * SSQ_SCALE);
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+    const int b = grp * 16 + r, row = b - b0;
+    const bool live = row >= 0 && row < rows;
+    const float rstd = rs[r];
+    const half_t* xr = x + (live ? row : 0) * ldx + g * 8;
+    half_t* dst = xf + ((int64_t)grp * K32 * 64 + lane) * 8;
+    for (int k0 = 0; k0 < K32; k0 += 8 * NWV) {                // batches of 8 tiles per wave: loads first, then math + stores
+        h8 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k32 = k0 + wv + i * NWV;
+            if (live && k32 < K32) t[i] = *(const h8*)(xr + k32 * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k32 = k0 + wv + i * NWV;
+            if (live && k32 < K32) {
+                h8 o = t[i];
+                if (w) {
+                    const float* wk = w + k32 * 32 + g * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)(wk[j] * (float)(half_t)((float)t[i][j] * rstd));
+                }
+                *(h8*)(dst + (int64_t)k32 * AUR_FRAG_HALVES) = o;
+            }
+        }
+    }
+}
+
+int g_xfrag_norm_waves = 16;
+hipError_t launch_xfrag_norm(const half_t* x, int64_t ldx, const float* w, float eps, int rows, int d, int b0, half_t* xf,
+                             unsigned long long* ssq_out, hipStream_t s) {
+    if ((d & 31) || rows < 1) return hipErrorInvalidValue;
+    const int g0 = b0 >> 4, g1 = (b0 + rows - 1) >> 4;
+    extern int g_xfrag_norm_waves;
+    if (g_xfrag_norm_waves == 16) hipLaunchKernelGGL(xfrag_norm_kernel<16>, dim3(g1 - g0 + 1), dim3(1024), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
+    else if (g_xfrag_norm_waves == 8) hipLaunchKernelGGL(xfrag_norm_kernel<8>, dim3(g1 - g0 + 1), dim3(512), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
+    else hipLaunchKernelGGL(xfrag_norm_kernel<4>, dim3(g1 - g0 + 1), dim3(256), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
+    return hipGetLastError();
+}
+
+// generic row-major [rows, d] -> x-fragment form for any d % 32 == 0 (test entry point / wide rows)
+__global__ void xfrag_pack_kernel(const half_t* __restrict__ x, int64_t ldx, int rows, int d, half_t* __restrict__ xf) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nchunk = d >> 3;
+    if (id >= (int64_t)rows * nchunk) return;
+    const int b = id / nchunk, cch = id % nchunk;
+    *(h8*)(xf + xfrag_piece(b, cch * 8, d >> 5)) = *(const h8*)(x + b * ldx + cch * 8);
+}
+hipError_t launch_xfrag_pack(const half_t* x, int64_t ldx, int rows, int d, half_t* xf, hipStream_t s) {
+    if (d & 31) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)rows * (d >> 3);
+    hipLaunchKernelGGL(xfrag_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, rows, d, xf);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ decode attention
@@ -492,7 +566,8 @@ __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
         num += wgt * a.part_o[(p0 + s) * a.hd + d];
         den += wgt * a.part_ml[(p0 + s) * 2 + 1];
     }
-    a.out[(int64_t)b * a.ldo + head * a.hd + d] = (half_t)(num / den);
+    const int k = head * a.hd + d;                 // attention output in x-fragment form (input of the o projection)
+    a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);
 }
 
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
@@ -511,16 +586,18 @@ hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ argmax + advance
-// Greedy step bookkeeping: token = first argmax of the fp32 logits; append to out_ids unless the sequence
-// already finished; EOS marks it finished; x_next[b] = embed[token]; pos[b] += advance_pos.
-__global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __restrict__ logits, int vocab,
+// Greedy step bookkeeping for slot b = b0 + blockIdx.x: token = first argmax of the fp32 logits; append to out_ids unless
+// the sequence already finished; EOS marks it finished; the next input x[b] = embed[token] is written in x-fragment
+// form together with sum(x^2) (2^-28 fixed point) for the first folded RMSNorm of the next step; pos[b] += advance_pos.
+__global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __restrict__ logits, int b0, int vocab,
                                                              const half_t* __restrict__ embed, int d, int eos_id, int max_new,
                                                              int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
                                                              int32_t* __restrict__ finished, int32_t* __restrict__ pos,
-                                                             half_t* __restrict__ x_next, int ldx, int advance_pos, int set_pos) {
+                                                             half_t* __restrict__ xf, unsigned long long* __restrict__ ssq,
+                                                             int advance_pos, int set_pos) {
     __shared__ float sv[256];
     __shared__ int si[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = b0 + blockIdx.x, tid = threadIdx.x;
     const float* lg = logits + (int64_t)b * vocab;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -547,6 +624,7 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __rest
     }
     int tok = si[0];
     if (tok == 0x7fffffff) tok = 0;
+    __syncthreads();
     if (tid == 0) {
         if (!finished[b]) {
             const int n = out_len[b];
@@ -559,14 +637,26 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __rest
         if (set_pos >= 0) pos[b] = set_pos;
         if (advance_pos) pos[b] += 1;
     }
-    for (int cidx = tid; cidx < (d >> 3); cidx += 256)
-        *(h8*)(x_next + (int64_t)b * ldx + cidx * 8) = *(const h8*)(embed + (int64_t)tok * d + cidx * 8);
+    float ss = 0.f;
+    for (int cidx = tid; cidx < (d >> 3); cidx += 256) {
+        const h8 v = *(const h8*)(embed + (int64_t)tok * d + cidx * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+        *(h8*)(xf + xfrag_piece(b, cidx * 8, d >> 5)) = v;
+    }
+    sv[tid] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {            // fixed-order tree: deterministic
+        if (tid < o) sv[tid] += sv[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) ssq[b] = (unsigned long long)__float2ll_rn(sv[0] * SSQ_SCALE);
 }
 
-hipError_t launch_argmax_advance(const float* logits, int B, int vocab, const half_t* embed, int d, int eos_id,
+hipError_t launch_argmax_advance(const float* logits, int b0, int nb, int vocab, const half_t* embed, int d, int eos_id,
                                  int max_new, int32_t* out_ids, int32_t* out_len, int32_t* finished, int32_t* pos,
-                                 half_t* x_next, int ldx, int advance_pos, int set_pos, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_advance_kernel, dim3(B), dim3(256), 0, s, logits, vocab, embed, d, eos_id, max_new, out_ids,
-                       out_len, finished, pos, x_next, ldx, advance_pos, set_pos);
+                                 half_t* xf, unsigned long long* ssq, int advance_pos, int set_pos, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_advance_kernel, dim3(nb), dim3(256), 0, s, logits, b0, vocab, embed, d, eos_id, max_new, out_ids,
+                       out_len, finished, pos, xf, ssq, advance_pos, set_pos);
     return hipGetLastError();
 }

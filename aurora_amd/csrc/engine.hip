@@ -61,13 +61,14 @@ struct aur_ctx {
     float *w_metric, *w_mhat, *w_nmax, *w_sza, *w_szb;
     int32_t *w_nidx, *w_unm, *w_src, *w_dst;
     // workspace regions (llm)
-    half_t *l_xn, *l_qf, *l_attn, *l_h, *l_p1, *d_x, *d_xn, *d_q, *d_attn, *d_h;
+    half_t *l_xn, *l_qf, *l_attn, *l_h, *l_p1, *d_x, *d_q, *d_attn, *d_h, *d_scr;
+    unsigned long long *s_ssq_mlp, *s_ssq_attn;
     float *d_logits, *d_part_o, *d_part_ml;
     float2* l_rope;
     int32_t *s_pos, *s_ids, *s_len, *s_fin, *s_ptab;
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
-    int fuse_norm = 0, attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
+    int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     // profiling
@@ -195,11 +196,14 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->l_h = k.take<half_t>(LP * g.llm_mlp);
     c->l_p1 = k.take<half_t>(LP * d);
     c->l_rope = k.take<float2>((int64_t)c->l_ctx_pad * (c->l_hd / 2));
-    c->d_x = k.take<half_t>(B * d);
-    c->d_xn = k.take<half_t>(B * d);
+    const int64_t Bp = rup((int)B, 16);                    // x-fragment buffers hold whole groups of 16 rows
+    c->d_x = k.take<half_t>(Bp * d);                       // residual stream    (x-fragment form)
+    c->s_ssq_mlp = k.take<unsigned long long>(32);         // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
+    c->s_ssq_attn = k.take<unsigned long long>(32);        // sum(x^2) per row after the attention residual
     c->d_q = k.take<half_t>(B * d);
-    c->d_attn = k.take<half_t>(B * d);
-    c->d_h = k.take<half_t>(B * g.llm_mlp);
+    c->d_attn = k.take<half_t>(Bp * d);                    // attention output  (x-fragment form)
+    c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
+    c->d_scr = k.take<half_t>(32 * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_logits = k.take<float>(B * g.llm_vocab);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
@@ -219,7 +223,7 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
         return aur_fail(nullptr, AUR_ERR_ARG, "vit dims: hidden/mlp must be multiples of 64, head_dim a multiple of 16");
     if (g.llm_hidden % 128 || g.llm_mlp % 128 || g.llm_hidden % g.llm_heads || (g.llm_hidden / g.llm_heads) % 32)
         return aur_fail(nullptr, AUR_ERR_ARG, "llm dims: hidden/mlp must be multiples of 128, head_dim a multiple of 32");
-    if (g.max_batch < 1 || g.max_batch > 16) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, 16]");
+    if (g.max_batch < 1 || g.max_batch > 32) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, 32]");
     if (g.page_tokens < 64 || g.page_tokens % 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be a multiple of 64");
     if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
     {
@@ -321,15 +325,14 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
     if (have_llm) {
         if (!ctx->kvpool) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: kv pool not set");
         const int64_t d = g.llm_hidden;
-        bool ok = get(ctx, "llm.embed", &ctx->l_embed, (int64_t)g.llm_vocab * d * 2) && get(ctx, "llm.norm.w", &ctx->l_norm_w, d * 4) &&
+        bool ok = get(ctx, "llm.embed", &ctx->l_embed, (int64_t)g.llm_vocab * d * 2) &&
                   get(ctx, "llm.lm_head.w", &ctx->l_head_w, (int64_t)ctx->l_vocab_pad * d * 2);
         if (!ok) return AUR_ERR_STATE;
         ctx->ll.assign(g.llm_layers, LlmLayerW{});
         for (int l = 0; l < g.llm_layers; ++l) {
             const std::string p = "llm." + std::to_string(l) + ".";
             LlmLayerW& w = ctx->ll[l];
-            ok = get(ctx, p + "ln1.w", &w.ln1_w, d * 4) && get(ctx, p + "ln2.w", &w.ln2_w, d * 4) &&
-                 get(ctx, p + "qkv.w", &w.qkv_w, (int64_t)ctx->l_qkv_npad * d * 2) && get(ctx, p + "o.w", &w.o_w, (int64_t)ctx->l_dpad * d * 2) &&
+            ok = get(ctx, p + "qkv.w", &w.qkv_w, (int64_t)ctx->l_qkv_npad * d * 2) && get(ctx, p + "o.w", &w.o_w, (int64_t)ctx->l_dpad * d * 2) &&
                  get(ctx, p + "gateup.w", &w.gateup_w, (int64_t)ctx->l_gu_npad * d * 2) &&
                  get(ctx, p + "down.w", &w.down_w, (int64_t)ctx->l_dpad * g.llm_mlp * 2);
             if (!ok) return AUR_ERR_STATE;
@@ -625,11 +628,16 @@ extern "C" int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, con
 }
 extern "C" int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
                                  int32_t n, float* out, void* stream) {
-    if (m < 1 || m > 16 || (k & 127) || (npad & 31) || n > npad || (n & 3)) return aur_fail(ctx, AUR_ERR_ARG, "aur_linear_skinny: need m <= 16, k %% 128 == 0");
+    if (m < 1 || m > 32 || (k & 127) || k > 16384 || (npad & 31) || n > npad || (n & 3))
+        return aur_fail(ctx, AUR_ERR_ARG, "aur_linear_skinny: need m <= 32, k %% 128 == 0, k <= 16384");
+    if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_linear_skinny: workspace not set");
+    hipStream_t st = (hipStream_t)stream;
+    CK(hipMemsetAsync(ctx->d_scr, 0, (size_t)32 * 16384 * 2, st));
+    CK(launch_xfrag_pack((const half_t*)a, k, m, k, ctx->d_scr, st));
     SkinnyArgs s{};
-    s.x = (const half_t*)a; s.ldx = k; s.W = (const half_t*)w_packed; s.B = m; s.Npad = npad; s.K = k; s.n_real = n;
+    s.xf = ctx->d_scr; s.W = (const half_t*)w_packed; s.B = m; s.b_lo = 0; s.b_hi = m; s.Npad = npad; s.K = k; s.n_real = n;
     s.mode = SK_LOGITS; s.out32 = out;
-    CK(launch_skinny(s, (hipStream_t)stream));
+    CK(launch_skinny(s, st));
     return AUR_OK;
 }
 extern "C" int aur_layernorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, const float* b, float eps,
@@ -701,18 +709,25 @@ extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_toke
     CK(hipMemsetAsync(ctx->s_fin, 0, (size_t)g.max_batch * 4, s));
     CK(hipMemsetAsync(ctx->s_pos, 0, (size_t)g.max_batch * 4, s));
     CK(hipMemsetAsync(ctx->s_ids, 0, (size_t)g.max_batch * g.max_new_tokens * 4, s));
+    const size_t bp = (size_t)rup(g.max_batch, 16);       // unused fragment lanes must hold finite values
+    CK(hipMemsetAsync(ctx->d_x, 0, bp * g.llm_hidden * 2, s));
+    CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, 32 * 8, s));
+    CK(hipMemsetAsync(ctx->s_ssq_attn, 0, 32 * 8, s));
+    CK(hipMemsetAsync(ctx->d_attn, 0, bp * g.llm_hidden * 2, s));
+    CK(hipMemsetAsync(ctx->d_h, 0, bp * g.llm_mlp * 2, s));
     return AUR_OK;
 }
 
-static int lm_head_and_advance(aur_ctx* ctx, const half_t* xn, int b0, int nb, int advance, int set_pos, hipStream_t s) {
+// logits for batch columns [b0, b0 + nb) from the residual rows in d_x (x-fragment form; final RMSNorm folded into the
+// lm_head weights, 1/rms from s_ssq_mlp), then greedy bookkeeping + next-token embedding
+static int lm_head_and_advance(aur_ctx* ctx, int b0, int nb, int advance, int set_pos, hipStream_t s) {
     const aur_config& g = ctx->cfg;
     SkinnyArgs h{};
-    h.x = xn; h.ldx = g.llm_hidden; h.W = ctx->l_head_w; h.B = nb; h.Npad = ctx->l_vocab_pad; h.K = g.llm_hidden; h.n_real = g.llm_vocab;
-    h.mode = SK_LOGITS; h.out32 = ctx->d_logits + (int64_t)b0 * g.llm_vocab;
+    h.xf = ctx->d_x; h.W = ctx->l_head_w; h.B = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = g.llm_hidden; h.n_real = g.llm_vocab;
+    h.mode = SK_LOGITS; h.out32 = ctx->d_logits; h.b_lo = b0; h.b_hi = b0 + nb; h.ssq_in = ctx->s_ssq_mlp; h.norm_eps = g.llm_rms_eps;
     CK(launch_skinny(h, s));
-    CK(launch_argmax_advance(ctx->d_logits + (int64_t)b0 * g.llm_vocab, nb, g.llm_vocab, ctx->l_embed, g.llm_hidden, ctx->eos, ctx->max_new,
-                             ctx->s_ids + (int64_t)b0 * ctx->max_new, ctx->s_len + b0, ctx->s_fin + b0, ctx->s_pos + b0,
-                             ctx->d_x + (int64_t)b0 * g.llm_hidden, g.llm_hidden, advance, set_pos, s));
+    CK(launch_argmax_advance(ctx->d_logits, b0, nb, g.llm_vocab, ctx->l_embed, g.llm_hidden, ctx->eos, ctx->max_new, ctx->s_ids, ctx->s_len,
+                             ctx->s_fin, ctx->s_pos, ctx->d_x, ctx->s_ssq_mlp, advance, set_pos, s));
     return AUR_OK;
 }
 
@@ -722,7 +737,7 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
     const aur_config& g = ctx->cfg;
     const LlmLayerW& w = ctx->ll[l];
     const int d = g.llm_hidden, Mseq = rup(seq_len, 32), M = nseq * Mseq;
-    if (which & 1) CK(launch_rmsnorm(x, d, w.ln1_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+    if (which & 1) CK(launch_rmsnorm(x, d, nullptr, g.llm_rms_eps, M, d, ctx->l_xn, d, s));      // weight folded into qkv.w
     if (which & 2) {
         GemmArgs q{};
         q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
@@ -742,7 +757,7 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
         o.n_real = d; o.act = ACT_NONE;
         CK(launch_gemm(o, EPI_ROW, s));
     }
-    if (which & 16) CK(launch_rmsnorm(x, d, w.ln2_w, g.llm_rms_eps, M, d, ctx->l_xn, d, s));
+    if (which & 16) CK(launch_rmsnorm(x, d, nullptr, g.llm_rms_eps, M, d, ctx->l_xn, d, s));     // weight folded into gateup.w
     if (which & 32) {
         GemmArgs gu{};
         gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
@@ -773,9 +788,9 @@ extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, 
         if (rc) return rc;
     }
     // logits of each sequence's last prompt position -> first generated tokens
-    half_t* xn1 = ctx->d_xn + (int64_t)slot0 * d;
-    CK(launch_rmsnorm(x + (int64_t)(seq_len - 1) * d, Mseq * d, ctx->l_norm_w, g.llm_rms_eps, nseq, d, xn1, d, s));
-    int rc = lm_head_and_advance(ctx, xn1, slot0, nseq, 0, seq_len, s);
+    // last prompt rows -> residual fragments + sum(x^2): the lm_head applies the (folded) final RMSNorm itself
+    CK(launch_xfrag_norm(x + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
+    int rc = lm_head_and_advance(ctx, slot0, nseq, 0, seq_len, s);
     if (rc) return rc;
     stage_end(ctx, "prefill", s);
     return AUR_OK;
@@ -789,10 +804,10 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden;
     SkinnyArgs q{};
-    q.x = ctx->fuse_norm ? ctx->d_x : ctx->d_xn; q.ldx = d; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
+    q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
+    q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
     q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr;
-    if (ctx->fuse_norm) { q.norm_w = ctx->ll[l].ln1_w; q.norm_eps = g.llm_rms_eps; }
     return q;
 }
 static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
@@ -800,31 +815,31 @@ static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
     DecAttnArgs at{};
     at.qbuf = ctx->d_q; at.kv = llm_kv(ctx, l); at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = ctx->batch; at.heads = g.llm_heads;
     at.hd = ctx->l_hd; at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
-    at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out = ctx->d_attn; at.ldo = g.llm_hidden; at.variant = ctx->attn_variant;
+    at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32; at.variant = ctx->attn_variant;
     return at;
 }
 static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     const int d = ctx->cfg.llm_hidden;
     SkinnyArgs o{};
-    o.x = ctx->d_attn; o.ldx = d; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d; o.mode = SK_ROW;
-    o.out = ctx->d_x; o.ldo = d; o.resid = ctx->d_x; o.ldr = d; o.waves = ctx->row_waves;
+    o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
+    o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden;
     SkinnyArgs gu{};
-    gu.x = ctx->fuse_norm ? ctx->d_x : ctx->d_xn; gu.ldx = d; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
-    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out = ctx->d_h; gu.ldo = g.llm_mlp;
-    if (ctx->fuse_norm) { gu.norm_w = ctx->ll[l].ln2_w; gu.norm_eps = g.llm_rms_eps; }
+    gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
+    gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32;
     return gu;
 }
 static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden;
     SkinnyArgs dn{};
-    dn.x = ctx->d_h; dn.ldx = g.llm_mlp; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.n_real = d;
-    dn.mode = SK_ROW; dn.out = ctx->d_x; dn.ldo = d; dn.resid = ctx->d_x; dn.ldr = d; dn.waves = ctx->row_waves;
+    dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
+    dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
     return dn;
 }
 
@@ -833,11 +848,9 @@ static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
     const int d = g.llm_hidden, B = ctx->batch;
     for (int l = 0; l < g.llm_layers; ++l) {
         const LlmLayerW& w = ctx->ll[l];
-        if (!ctx->fuse_norm) CK(launch_rmsnorm(ctx->d_x, d, w.ln1_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
         CK(launch_skinny(mk_dec_qkv(ctx, l), s));
         CK(launch_decode_attention(mk_dec_attn(ctx, l), s));
         CK(launch_skinny(mk_dec_o(ctx, l), s));
-        if (!ctx->fuse_norm) CK(launch_rmsnorm(ctx->d_x, d, w.ln2_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
         SkinnyArgs gu = mk_dec_gateup(ctx, l);
         if (instrument) {
             if (ctx->kev_used == ctx->kev.size()) {
@@ -856,8 +869,7 @@ static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
         }
         CK(launch_skinny(mk_dec_down(ctx, l), s));
     }
-    CK(launch_rmsnorm(ctx->d_x, d, ctx->l_norm_w, g.llm_rms_eps, B, d, ctx->d_xn, d, s));
-    return lm_head_and_advance(ctx, ctx->d_xn, 0, B, 1, -1, s);
+    return lm_head_and_advance(ctx, 0, B, 1, -1, s);
 }
 
 extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
@@ -919,10 +931,10 @@ extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
 
 // ------------------------------------------------------------------------------------------ tuning / microbench
 extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
-    if (!strcmp(name, "fuse_norm")) ctx->fuse_norm = value != 0;
-    else if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
+    if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
+
     else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
@@ -950,16 +962,16 @@ extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, d
     CK(hipEventCreate(&e1));
     auto run = [&](int i) -> int {
         const int l = i % nl;
-        if (!strcmp(kernel, "dec_norm")) { CK(launch_rmsnorm(ctx->d_x, d, ctx->ll[l].ln1_w, g.llm_rms_eps, ctx->batch, d, ctx->d_xn, d, s)); }
-        else if (!strcmp(kernel, "dec_qkv")) { CK(launch_skinny(mk_dec_qkv(ctx, l), s)); }
+        if (!strcmp(kernel, "dec_qkv")) { CK(launch_skinny(mk_dec_qkv(ctx, l), s)); }
         else if (!strcmp(kernel, "dec_attn")) { CK(launch_decode_attention(mk_dec_attn(ctx, l), s)); }
         else if (!strcmp(kernel, "dec_o")) { CK(launch_skinny(mk_dec_o(ctx, l), s)); }
         else if (!strcmp(kernel, "dec_gateup")) { CK(launch_skinny(mk_dec_gateup(ctx, l), s)); }
         else if (!strcmp(kernel, "dec_down")) { CK(launch_skinny(mk_dec_down(ctx, l), s)); }
         else if (!strcmp(kernel, "dec_lm_head")) {
             SkinnyArgs h{};
-            h.x = ctx->d_xn; h.ldx = d; h.W = ctx->l_head_w; h.B = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = d; h.n_real = g.llm_vocab;
-            h.mode = SK_LOGITS; h.out32 = ctx->d_logits;
+            h.ssq_in = ctx->s_ssq_mlp; h.norm_eps = g.llm_rms_eps;
+            h.xf = ctx->d_x; h.W = ctx->l_head_w; h.B = ctx->batch; h.b_lo = 0; h.b_hi = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = d;
+            h.n_real = g.llm_vocab; h.mode = SK_LOGITS; h.out32 = ctx->d_logits;
             CK(launch_skinny(h, s));
         } else {
             int bit = !strcmp(kernel, "pre_norm") ? 1 : !strcmp(kernel, "pre_qkv") ? 2 : !strcmp(kernel, "pre_attn") ? 4 : !strcmp(kernel, "pre_o") ? 8

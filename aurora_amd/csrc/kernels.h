@@ -106,19 +106,20 @@ hipError_t launch_embed_rows(const half_t* table, int d, const int32_t* ids, con
 
 // ---- decode.hip
 struct SkinnyArgs {
-    const half_t* x;        // [B, K] row-major
-    int ldx;
+    const half_t* xf;       // activations in x-fragment form [ceil(B/16)][K/32][64][8], lane = g*16 + (b % 16)
     const half_t* W;        // FRAG-packed [Npad/16][K/32][512]
     int B, Npad, K, n_real;
     int mode;               // SK_ROW, SK_LOGITS, SK_SILU_MUL, SK_QKV
-    half_t* out;            // SK_ROW / SK_SILU_MUL: [B, ldo]
-    int ldo;
-    const half_t* resid;    // optional [B, ldr]
-    int ldr;
-    float* out32;           // SK_LOGITS: [B, n_real] fp32
-    const float* norm_w;    // optional fused RMSNorm over x rows (weight [K]); requires the row length == K
-    float norm_eps;
     int waves;              // SK_ROW: 4 (default) or 8 waves per workgroup
+    int b_lo, b_hi;         // only batch columns b_lo <= b < b_hi are stored
+    half_t* xres;           // SK_ROW: residual stream in x-fragment form (K32 = n_real/32), updated in place: x += y
+    unsigned long long* ssq_out;        // SK_ROW: sum(x_new^2) per row, 2^-28 fixed point, accumulated with integer atomics
+    const unsigned long long* ssq_in;   // folded RMSNorm: sum(x^2) of the input rows -> acc *= rsqrt(ssq/K + eps); nullptr = none
+    unsigned long long* ssq_zero;       // accumulator (32 entries) to reset for a later kernel; nullptr = none
+    float norm_eps;
+    half_t* out_f;          // SK_SILU_MUL: x-fragment form with K32 = out_k32 (input of the down projection)
+    int out_k32;
+    float* out32;           // SK_LOGITS: [B, n_real] fp32
     // SK_QKV
     int q_cols, k_cols, hd;
     half_t* qbuf;           // [B][heads][kblk][4][8]   (PAIRED-d pieces)
@@ -129,6 +130,10 @@ struct SkinnyArgs {
 };
 enum { SK_ROW = 0, SK_LOGITS = 1, SK_SILU_MUL = 2, SK_QKV = 3 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// xf[b0 + row] = RMSNorm(x[row]) (w != nullptr) or x[row], in x-fragment form; x rows are ldx halves apart
+hipError_t launch_xfrag_norm(const half_t* x, int64_t ldx, const float* w, float eps, int rows, int d, int b0, half_t* xf,
+                             unsigned long long* ssq_out, hipStream_t s);
+hipError_t launch_xfrag_pack(const half_t* x, int64_t ldx, int rows, int d, half_t* xf, hipStream_t s);
 
 struct DecAttnArgs {
     const half_t* qbuf;     // [B][heads][kblk][4][8]
@@ -140,12 +145,12 @@ struct DecAttnArgs {
     float scale;
     float* part_o;          // [B][heads][nsplit][hd]
     float* part_ml;         // [B][heads][nsplit][2]
-    half_t* out;            // [B, heads*hd]
-    int ldo;
+    half_t* out_f;          // [B, heads*hd] in x-fragment form (K32 = out_k32 = heads*hd/32)
+    int out_k32;
     int variant;            // 0: load-use per page; 1: software-pipelined (next page's K + this page's V in flight)
 };
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);
 
-hipError_t launch_argmax_advance(const float* logits, int B, int vocab, const half_t* embed, int d, int eos_id,
+hipError_t launch_argmax_advance(const float* logits, int b0, int nb, int vocab, const half_t* embed, int d, int eos_id,
                                  int max_new, int32_t* out_ids, int32_t* out_len, int32_t* finished, int32_t* pos,
-                                 half_t* x_next, int ldx, int advance_pos, int set_pos, hipStream_t s);
+                                 half_t* xf, unsigned long long* ssq, int advance_pos, int set_pos, hipStream_t s);

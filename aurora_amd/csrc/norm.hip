@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const half_t* __restrict__ x,
                 float t = (v[i][j] - mean) * rstd;
                 if (RMS) {
                     // HF: weight * hidden.to(input_dtype): round the normalised value to fp16 first
-                    t = w[k] * (float)(half_t)t;
+                    t = (w ? w[k] : 1.0f) * (float)(half_t)t;      // w == nullptr: weight folded into the consumer
                 } else {
                     t = t * w[k] + b[k];
                 }

@@ -219,18 +219,21 @@ class AuroraCapEngine:
         rm_gu = np.full(gu_npad, -1, np.int32)
         rm_gu[0: 2 * mlp: 2] = np.arange(mlp)
         rm_gu[1: 2 * mlp: 2] = mlp + np.arange(mlp)
+        # RMSNorm weights are FOLDED into the projection that consumes the normalised activations:
+        #   W (w_norm * x_hat) = (W diag(w_norm)) x_hat.  The kernels then only need the per-row 1/rms
+        #   (prefill: weight-less norm kernel; decode: sum(x^2) carried by the residual-producing epilogues).
+        def fold(wmat, wnorm):
+            return (wmat.detach().to(self.dev, torch.float32) * wnorm.detach().to(self.dev, torch.float32)[None, :]).to(torch.float16)
+
         self._set("llm.embed", self._h(w["embed_tokens.weight"]))
-        self._set("llm.norm.w", self._f(w["norm.weight"]))
-        self._set("llm.lm_head.w", self.pack(w["lm_head.weight"], vpad, d))
+        self._set("llm.lm_head.w", self.pack(fold(w["lm_head.weight"], w["norm.weight"]), vpad, d))
         for i, lw in enumerate(w["layers"]):
             p = f"llm.{i}."
-            self._set(p + "ln1.w", self._f(lw["input_layernorm.weight"]))
-            self._set(p + "ln2.w", self._f(lw["post_attention_layernorm.weight"]))
             wqkv = torch.cat([lw["q_proj.weight"], lw["k_proj.weight"], lw["v_proj.weight"]], 0)
-            self._set(p + "qkv.w", self.pack(wqkv, qkv_npad, d, rm_qkv))
+            self._set(p + "qkv.w", self.pack(fold(wqkv, lw["input_layernorm.weight"]), qkv_npad, d, rm_qkv))
             self._set(p + "o.w", self.pack(lw["o_proj.weight"], dpad, d))
             wgu = torch.cat([lw["gate_proj.weight"], lw["up_proj.weight"]], 0)
-            self._set(p + "gateup.w", self.pack(wgu, gu_npad, d, rm_gu))
+            self._set(p + "gateup.w", self.pack(fold(wgu, lw["post_attention_layernorm.weight"]), gu_npad, d, rm_gu))
             self._set(p + "down.w", self.pack(lw["down_proj.weight"], dpad, mlp))
 
     def _load_projector(self, w: dict):

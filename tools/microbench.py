@@ -43,7 +43,6 @@ def main():
     M = _rup(L0, 32)
     kv_bytes = B * (L0 + 1) * 2 * d * 2
     work = {   # kernel -> (unit, amount per launch)
-        "dec_norm": ("GB/s", 2 * B * d * 2),
         "dec_qkv": ("GB/s", 3 * d * d * 2), "dec_o": ("GB/s", d * d * 2), "dec_gateup": ("GB/s", 2 * mlp * d * 2),
         "dec_down": ("GB/s", mlp * d * 2), "dec_lm_head": ("GB/s", V * d * 2), "dec_attn": ("GB/s", kv_bytes),
         "pre_qkv": ("TF/s", 2 * M * 3 * d * d), "pre_o": ("TF/s", 2 * M * d * d), "pre_gateup": ("TF/s", 2 * M * 2 * mlp * d),
@@ -61,16 +60,12 @@ def main():
             res[f"{tag}:{k}"] = (round(us, 2), round(rate, 1), unit)
             print(f"{tag:28s} {k:12s} {us:9.2f} us  {rate:9.1f} {unit}", flush=True)
 
-    dec = ["dec_norm", "dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
-    eng.set_option("fuse_norm", 0)
-    run("unfused-norm", dec)
-    for nw in (4, 8):
-        eng.set_option("dec_row_waves", nw)
-        run(f"row kernels {nw} waves", ["dec_o", "dec_down"])
+    dec = ["dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
+    run("decode", dec)
     if not args.quick:
-        eng.set_option("fuse_norm", 1)
-        run("fused-norm", ["dec_qkv", "dec_gateup"])
-        eng.set_option("fuse_norm", 0)
+        for nw in (4, 8):
+            eng.set_option("dec_row_waves", nw)
+            run(f"row kernels {nw} waves", ["dec_o", "dec_down"])
         for variant in (0, 1):
             eng.set_option("dec_attn_variant", variant)
             for pps in (1, 2, 4, 8):
