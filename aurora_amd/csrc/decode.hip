@@ -570,7 +570,7 @@ __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);
 }
 
-hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
+hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     if (a.kv.page_tokens & 63) return hipErrorInvalidValue;
     dim3 grid(a.nsplit, a.heads, a.B);
     const bool pipe = a.variant == 1 && a.kv.page_tokens == 64;
@@ -581,8 +581,15 @@ hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
     else if (a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_kernel<1, 2>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.heads, a.B), dim3(a.hd <= 64 ? 64 : 128), 0, s, a);
     return hipGetLastError();
+}
+hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s) {
+    hipError_t e = launch_decode_attention_main(a, s);
+    return e != hipSuccess ? e : launch_decode_attention_combine(a, s);
 }
 
 // ------------------------------------------------------------------------------------ argmax + advance

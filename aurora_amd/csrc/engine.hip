@@ -74,10 +74,12 @@ struct aur_ctx {
     // profiling
     bool prof = false;
     std::unordered_map<std::string, StageTimer> timers;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;   // event pairs around the dominant decode kernel
-    size_t kev_used = 0;
-    double kev_ms = 0;
-    int64_t kev_n = 0;
+    struct KernelEvents {                                // HIP-event pairs around every launch of one decode kernel
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        size_t used = 0;
+        double ms = 0;
+        int64_t n = 0;
+    } kev[2];                                            // 0: decode attention (main kernel), 1: gate/up GEMV
 };
 
 static std::string g_create_err;
@@ -246,10 +248,11 @@ extern "C" void aur_destroy(aur_ctx* ctx) {
         if (kv.second.e0) hipEventDestroy(kv.second.e0);
         if (kv.second.e1) hipEventDestroy(kv.second.e1);
     }
-    for (auto& p : ctx->kev) {
-        hipEventDestroy(p.first);
-        hipEventDestroy(p.second);
-    }
+    for (auto& kv : ctx->kev)
+        for (auto& p : kv.ev) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
     delete ctx;
 }
 
@@ -403,27 +406,44 @@ extern "C" int aur_profile_enable(aur_ctx* ctx, int32_t on) {
         kv.second.launches = 0;
         kv.second.open = false;
     }
-    ctx->kev_used = 0;
-    ctx->kev_ms = 0;
-    ctx->kev_n = 0;
+    for (auto& kv : ctx->kev) {
+        kv.used = 0;
+        kv.ms = 0;
+        kv.n = 0;
+    }
     return AUR_OK;
 }
-static void kev_fold(aur_ctx* c) {
-    for (size_t i = 0; i < c->kev_used; ++i) {
-        hipEventSynchronize(c->kev[i].second);
+static void kev_fold(aur_ctx::KernelEvents& k) {
+    for (size_t i = 0; i < k.used; ++i) {
+        hipEventSynchronize(k.ev[i].second);
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->kev[i].first, c->kev[i].second) == hipSuccess) {
-            c->kev_ms += ms;
-            c->kev_n++;
+        if (hipEventElapsedTime(&ms, k.ev[i].first, k.ev[i].second) == hipSuccess) {
+            k.ms += ms;
+            k.n++;
         }
     }
-    c->kev_used = 0;
+    k.used = 0;
+}
+static void kev_begin(aur_ctx::KernelEvents& k, hipStream_t s) {
+    if (k.used == k.ev.size()) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        k.ev.push_back({a, b});
+    }
+    hipEventRecord(k.ev[k.used].first, s);
+}
+static void kev_end(aur_ctx::KernelEvents& k, hipStream_t s) {
+    hipEventRecord(k.ev[k.used].second, s);
+    k.used++;
+    if (k.used >= 4096) kev_fold(k);
 }
 extern "C" int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out, int64_t* launches_out) {
-    if (!strcmp(stage, "decode_gemm_gateup")) {
-        kev_fold(ctx);
-        if (ms_out) *ms_out = ctx->kev_ms;
-        if (launches_out) *launches_out = ctx->kev_n;
+    const int which = !strcmp(stage, "decode_attn") ? 0 : !strcmp(stage, "decode_gemm_gateup") ? 1 : -1;
+    if (which >= 0) {
+        kev_fold(ctx->kev[which]);
+        if (ms_out) *ms_out = ctx->kev[which].ms;
+        if (launches_out) *launches_out = ctx->kev[which].n;
         return AUR_OK;
     }
     auto it = ctx->timers.find(stage);
@@ -849,24 +869,18 @@ static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
     for (int l = 0; l < g.llm_layers; ++l) {
         const LlmLayerW& w = ctx->ll[l];
         CK(launch_skinny(mk_dec_qkv(ctx, l), s));
-        CK(launch_decode_attention(mk_dec_attn(ctx, l), s));
+        {
+            const DecAttnArgs at = mk_dec_attn(ctx, l);
+            if (instrument) kev_begin(ctx->kev[0], s);
+            CK(launch_decode_attention_main(at, s));
+            if (instrument) kev_end(ctx->kev[0], s);
+            CK(launch_decode_attention_combine(at, s));
+        }
         CK(launch_skinny(mk_dec_o(ctx, l), s));
         SkinnyArgs gu = mk_dec_gateup(ctx, l);
-        if (instrument) {
-            if (ctx->kev_used == ctx->kev.size()) {
-                hipEvent_t a, b;
-                hipEventCreate(&a);
-                hipEventCreate(&b);
-                ctx->kev.push_back({a, b});
-            }
-            hipEventRecord(ctx->kev[ctx->kev_used].first, s);
-        }
+        if (instrument) kev_begin(ctx->kev[1], s);
         CK(launch_skinny(gu, s));
-        if (instrument) {
-            hipEventRecord(ctx->kev[ctx->kev_used].second, s);
-            ctx->kev_used++;
-            if (ctx->kev_used >= 4096) kev_fold(ctx);
-        }
+        if (instrument) kev_end(ctx->kev[1], s);
         CK(launch_skinny(mk_dec_down(ctx, l), s));
     }
     return lm_head_and_advance(ctx, 0, B, 1, -1, s);

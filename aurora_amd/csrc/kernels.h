@@ -149,7 +149,9 @@ struct DecAttnArgs {
     int out_k32;
     int variant;            // 0: load-use per page; 1: software-pipelined (next page's K + this page's V in flight)
 };
-hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);
+hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);            // main + combine
+hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s);
+hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s);
 
 hipError_t launch_argmax_advance(const float* logits, int b0, int nb, int vocab, const half_t* embed, int d, int eos_id,
                                  int max_new, int32_t* out_ids, int32_t* out_len, int32_t* finished, int32_t* pos,

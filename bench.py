@@ -27,13 +27,13 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
+    p.add_argument("--batch", type=int, default=32, help="clips per GPU per step (decode slots; <= 32)")
     p.add_argument("--num_frm", type=int, default=8)
     p.add_argument("--token_kept_ratio", type=float, default=0.3)
     p.add_argument("--max_new_tokens", type=int, default=256)
-    p.add_argument("--prefill-group", type=int, default=4, help="clips prefetched per prefill pass (equal-length prompts)")
+    p.add_argument("--prefill-group", type=int, default=8, help="clips prefetched per prefill pass (equal-length prompts)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
@@ -206,19 +206,47 @@ def main():
         eng.profile(True)
         step()
         stages = {k: eng.profile_read(k)[0] for k in ("vit", "project", "prefill", "decode")}
+        ams, an = eng.profile_read("decode_attn")
         kms, kn = eng.profile_read("decode_gemm_gateup")
         eng.profile(False)
         result["stage_ms_instrumented_step"] = stages
-        d, mlp = l["hidden_size"], l["intermediate_size"]
-        wbytes = 2 * mlp * d * 2                                   # gate+up rows, fp16
-        alg = wbytes + B * d * 2 + B * mlp * 2                     # + x in + h out
+        d, mlp, H = l["hidden_size"], l["intermediate_size"], l["num_attention_heads"]
+        how = "HIP events around every launch of this kernel in one extra eager step on the launch stream (after the timed steps)"
+        pmc = {}
+        try:                                                       # rocprofv3 --pmc summary of this same command, if committed
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+        roof = {}
+        if an > 0:
+            # decode attention: K + V of every cached token of every sequence, all heads, read once per layer-step.
+            # context of a sequence at decode step s (1..N-1) is L0 + s keys -> mean over the N-1 steps of one generation
+            mean_ctx = L0 + N / 2.0
+            alg = B * mean_ctx * 2 * d * 2                               # K + V bytes (q and the split partials are < 0.1 %)
+            avg_s = ams / an * 1e-3
+            roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_pipe_kernel<4, 8> (paged decode attention)",
+                                   "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
+                                   "traffic": (pmc["decode_attn_pipe_kernel"]["bytes_per_launch"] * (B * mean_ctx) /
+                                               (pmc["_batch"] * pmc["_ctx_tokens"])) if "decode_attn_pipe_kernel" in pmc else None,
+                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/pmc_traffic.json, "
+                                                   "scaled linearly from its batch x context to this run's",
+                                   "algorithmic_bytes_per_launch": alg,
+                                   "avg_launch_us": avg_s * 1e6, "launches_timed": an, "how": how}
         if kn > 0:
+            alg = 2 * mlp * d * 2 + B * d * 2 + B * mlp * 2           # gate+up rows fp16 + x in + h out
             avg_s = kms / kn * 1e-3
-            result["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel<2, SK_SILU_MUL> (decode gate/up projection)",
-                                  "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                  "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6,
-                                  "launches_timed": kn,
-                                  "how": "HIP events around every launch of this kernel in one extra eager step on the launch stream"}
+            roof["decode_gateup"] = {"bound": "hbm", "kernel": "skinny_kernel<2, SK_SILU_MUL> (decode gate/up projection)",
+                                     "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
+                                     "traffic": pmc["skinny_kernel_gateup"]["bytes_per_launch"] if "skinny_kernel_gateup" in pmc else None,
+                                     "algorithmic_bytes_per_launch": alg,
+                                     "avg_launch_us": avg_s * 1e6, "launches_timed": kn, "how": how}
+        # the dominant kernel = the one with the larger total time in the decode loop
+        if roof:
+            dom = max(roof, key=lambda k: roof[k]["avg_launch_us"] * roof[k]["launches_timed"])
+            result["roofline"] = roof[dom]
+            for k, v in roof.items():
+                if k != dom:
+                    result["roofline_" + k] = v
         # single-clip latency (batch 1): TTFT without queueing behind other clips' ViT/prefill
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
