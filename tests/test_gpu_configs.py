@@ -1,0 +1,128 @@
+"""GPU parity at the BASELINE.json configurations' real WIDTHS and token schedules (depth reduced so that the CPU
+oracle finishes in seconds), plus size-independent properties at full size:
+
+  cfg2  8 frames, token_kept_ratio 0.3 -> r = 15, 264 tokens/frame, prefix 2142
+  cfg3 16 frames, ratio 0.2            -> r = 18, 171 tokens/frame (merge-dominated)
+  cfg5  8 frames, ratio 0.8            -> r = 4, 605 tokens/frame, 2048 new tokens (long KV, many pages / splits)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aurora_oracle as O
+from oracle import tome_ref
+from tests.util import rand_llm_weights, rand_vit_weights, rel_l2, to_match
+
+pytestmark = pytest.mark.gpu
+
+VIT_H = dict(hidden_size=1280, num_attention_heads=16, num_hidden_layers=3, intermediate_size=5120, patch_size=14,
+             image_size=378, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+LLAMA_7B_WIDTH = dict(hidden_size=4096, num_attention_heads=32, num_hidden_layers=2, intermediate_size=11008, vocab_size=32000,
+                      rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=4.0)
+
+
+def test_schedule_of_every_baseline_config():
+    from aurora_amd.engine import tokens_at_layer, tome_r
+    for ratio, r, kept in ((0.3, 15, 264), (0.2, 18, 171), (0.8, 4, 605), (1.0, 0, 729)):
+        assert tome_r(378, 378, 14, ratio, 32) == r
+        assert tokens_at_layer(730, r, 31) - 1 == kept
+
+
+@pytest.mark.parametrize("ratio,frames", [(0.3, 2), (0.2, 2), (0.8, 1)])
+def test_vit_h_width_layers_teacher_forced(ratio, frames):
+    """ViT-H/14-378 width (D 1280, 16 x 80, MLP 5120, 730 tokens): two real layers per config ratio, teacher-forced."""
+    from aurora_amd.engine import AuroraCapEngine, tome_r
+    w = rand_vit_weights(VIT_H, 7, wstd=0.02)
+    eng = AuroraCapEngine({"vit": VIT_H, "llm": None}, {"vit": w}, max_frames=frames, max_batch=1, max_ctx=128, max_new_tokens=8)
+    try:
+        r = tome_r(378, 378, 14, ratio, 32)
+        x = torch.randn(frames, 730, 1280, generator=torch.Generator().manual_seed(5)).half().float()
+        size = None
+        for layer in range(2):
+            xo, so, metric, idx = eng.vit_layer(layer, x, size, r)
+            mc = tome_ref.match(metric.cpu().numpy(), r)
+            for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+                np.testing.assert_array_equal(idx[k].cpu().numpy(), mc[k], err_msg=f"layer {layer} {k}")
+            xr, sr = O.vit_layer(x, size, w["layers"][layer], 16, r, "quick_gelu", forced_match=to_match(idx))
+            assert rel_l2(xo.float().cpu(), xr) < 5e-3
+            assert xo.shape[1] == x.shape[1] - r
+            x, size = xo.float().cpu(), so.cpu()[..., None]
+    finally:
+        eng.close()
+
+
+def test_llama_7b_width_prefill_and_decode_logits():
+    """Llama-7B width (d 4096, 32 x 128, MLP 11008, vocab 32000), 2 layers: prefill of a 2142-row prefix shape is too slow
+    for the CPU oracle, so a 300-token prefix checks logits; the 2142-token prefix checks bitwise properties."""
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.test_gpu_llm import LOGIT_TOL, padded, teacher_forced_logits
+    cfg = LLAMA_7B_WIDTH
+    w = rand_llm_weights(cfg, 3, wstd=0.02)
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=4, max_ctx=2560, max_new_tokens=16)
+    try:
+        emb = (torch.randn(300, 4096, generator=torch.Generator().manual_seed(1)) * 0.5).half().float()
+        eng.begin_batch(1, 6, None)
+        eng.prefill(0, padded(emb), 300)
+        logits = [eng.logits()[0].cpu()]
+        for _ in range(5):
+            eng.decode(1)
+            logits.append(eng.logits()[0].cpu())
+        ids = eng.outputs()[0]
+        ref = teacher_forced_logits(emb, ids, w, cfg)
+        scale = ref.abs().max().item()
+        for i in range(6):
+            assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, i
+        # cfg2 prefix length (2142): batched prefill == per-slot prefill, graph decode deterministic
+        g = torch.Generator().manual_seed(2)
+        embs = [(torch.randn(2142, 4096, generator=g) * 0.5).half() for _ in range(3)]
+        big = torch.cat([padded(e.float()) for e in embs], 0).contiguous()
+        eng.begin_batch(3, 16, None)
+        eng.prefill_batch(0, 3, big, 2142)
+        eng.decode(15)
+        a = eng.outputs()
+        eng.begin_batch(3, 16, None)
+        for b in range(3):
+            eng.prefill(b, padded(embs[b].float()), 2142)
+        eng.decode(15)
+        assert eng.outputs() == a and all(len(x) == 16 for x in a)
+    finally:
+        eng.close()
+
+
+def test_long_kv_decode_many_pages_cfg5_shape():
+    """cfg5 shape: prefix 4870, 2048 new tokens (context grows to 6.9k = 108 pages, 27 attention splits) on a small-width
+    model: teacher-forced logits at the start, middle and end of the generation, graph == eager."""
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.test_gpu_llm import LLM_CFGS, LOGIT_TOL, padded
+    cfg = LLM_CFGS["hd32"]
+    w = rand_llm_weights(cfg, 8)
+    L0, N = 4870, 2048
+    emb = torch.randn(L0, cfg["hidden_size"], generator=torch.Generator().manual_seed(6)).half().float()
+    outs = []
+    for use_graph in (True, False):
+        eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=1, max_ctx=7040, max_new_tokens=N,
+                              use_graph=use_graph)
+        try:
+            eng.begin_batch(1, N, None)
+            eng.prefill(0, padded(emb), L0)
+            if use_graph:
+                eng.decode(N - 2)
+                eng.decode(1)                      # last step separately: logits of the final position
+                last_logits = eng.logits()[0].cpu()
+            else:
+                eng.decode(N - 1)
+            outs.append(eng.outputs()[0])
+        finally:
+            eng.close()
+    assert len(outs[0]) == N and outs[0] == outs[1]
+    ids = outs[0]
+    full = torch.cat([emb, w["embed_tokens.weight"][torch.tensor(ids[:-1], dtype=torch.long)]], 0)
+    h, _ = O.llama_forward(full, w, cfg, None, 0)
+    ref_last = torch.nn.functional.linear(h[-1:], w["lm_head.weight"])[0]
+    assert (last_logits - ref_last).abs().max().item() <= LOGIT_TOL * ref_last.abs().max().item()
+    # every generated token is the first argmax of logits that agree with the oracle wherever its margin is clear
+    ref_all = torch.nn.functional.linear(h[L0 - 1:], w["lm_head.weight"])
+    top2 = ref_all.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL * ref_all.abs().max()
+    agree = (ref_all.argmax(-1) == torch.tensor(ids))
+    assert bool(agree[clear].all()) and int(clear.sum()) > N // 2
