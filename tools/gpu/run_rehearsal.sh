@@ -2,7 +2,7 @@
 # What the driver runs at round end: pytest -m gpu, smoke(), default bench.
 mkdir -p gpurun_out
 echo "=== pytest -m gpu" | tee gpurun_out/rehearsal.log
-echo skipped
+timeout 1500 python -m pytest tests/ -x -q -m gpu --no-header -p no:cacheprovider 2>&1 | tail -5 | tee -a gpurun_out/rehearsal.log
 echo "=== smoke" | tee -a gpurun_out/rehearsal.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee -a gpurun_out/rehearsal.log
 echo "=== default bench" | tee -a gpurun_out/rehearsal.log
