@@ -24,7 +24,7 @@ class AurConfig(C.Structure):
         ("llm_vocab", C.c_int32),
         ("llm_rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_factor", C.c_float),
         ("max_frames", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32),
-        ("page_tokens", C.c_int32), ("use_graph", C.c_int32),
+        ("page_tokens", C.c_int32), ("use_graph", C.c_int32), ("num_banks", C.c_int32),
     ]
 
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "aur_vit_encode": (C.c_int, [_P, _P, _I, _I, _P, _IP, _P]),
     "aur_project_splice": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "aur_begin_batch": (C.c_int, [_P, _I, _I, _I, _P]),
+    "aur_select_bank": (C.c_int, [_P, _I]),
     "aur_llm_prefill": (C.c_int, [_P, _I, _P, _I, _P]),
     "aur_llm_prefill_batch": (C.c_int, [_P, _I, _I, _P, _I, _P]),
     "aur_llm_decode": (C.c_int, [_P, _I, _P]),

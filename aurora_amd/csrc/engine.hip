@@ -71,6 +71,21 @@ struct aur_ctx {
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
+    // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
+    // that one batch can decode on one stream while the next batch's ViT + prefill run on another.  The members above
+    // (d_x, s_*, d_logits, batch, max_new, eos, graph, ...) always alias the CURRENT bank (aur_select_bank).
+    struct Bank {
+        half_t* d_x;
+        unsigned long long *s_ssq_mlp, *s_ssq_attn;
+        float* d_logits;
+        int32_t *s_pos, *s_ids, *s_len, *s_fin;
+        const int32_t* ptab;
+        int batch = 0, max_new = 0, eos = -1;
+        hipGraphExec_t graph = nullptr;
+        int graph_batch = 0;
+    } banks[2];
+    int nbanks = 1, cur_bank = 0;
+    const int32_t* ptab_cur = nullptr;
     // profiling
     bool prof = false;
     std::unordered_map<std::string, StageTimer> timers;
@@ -158,7 +173,8 @@ static void derive(aur_ctx* c) {
     c->l_max_pages = (g.max_ctx + g.page_tokens - 1) / g.page_tokens;
     c->l_ctx_pad = c->l_max_pages * g.page_tokens;
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
-    c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch;
+    c->nbanks = g.num_banks == 2 ? 2 : 1;
+    c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch * c->nbanks;
     // decode attention split: ~256 tokens per split
     c->pps = (256 + g.page_tokens - 1) / g.page_tokens;
     c->nsplit = (c->l_max_pages + c->pps - 1) / c->pps;
@@ -199,21 +215,30 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->l_p1 = k.take<half_t>(LP * d);
     c->l_rope = k.take<float2>((int64_t)c->l_ctx_pad * (c->l_hd / 2));
     const int64_t Bp = rup((int)B, 16);                    // x-fragment buffers hold whole groups of 16 rows
-    c->d_x = k.take<half_t>(Bp * d);                       // residual stream    (x-fragment form)
-    c->s_ssq_mlp = k.take<unsigned long long>(32);         // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
-    c->s_ssq_attn = k.take<unsigned long long>(32);        // sum(x^2) per row after the attention residual
+    for (int bk = 0; bk < 2; ++bk) {
+        aur_ctx::Bank& K = c->banks[bk];
+        K.d_x = k.take<half_t>(Bp * d);                    // residual stream    (x-fragment form)
+        K.s_ssq_mlp = k.take<unsigned long long>(32);      // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
+        K.s_ssq_attn = k.take<unsigned long long>(32);     // sum(x^2) per row after the attention residual
+        K.d_logits = k.take<float>(B * g.llm_vocab);
+        K.s_pos = k.take<int32_t>(B);
+        K.s_ids = k.take<int32_t>(B * g.max_new_tokens);
+        K.s_len = k.take<int32_t>(B);
+        K.s_fin = k.take<int32_t>(B);
+    }
     c->d_q = k.take<half_t>(B * d);
     c->d_attn = k.take<half_t>(Bp * d);                    // attention output  (x-fragment form)
     c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
     c->d_scr = k.take<half_t>(32 * 16384);                 // scratch x-fragments for aur_linear_skinny
-    c->d_logits = k.take<float>(B * g.llm_vocab);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
-    c->s_pos = k.take<int32_t>(B);
-    c->s_ids = k.take<int32_t>(B * g.max_new_tokens);
-    c->s_len = k.take<int32_t>(B);
-    c->s_fin = k.take<int32_t>(B);
-    c->s_ptab = k.take<int32_t>(B * c->l_max_pages);
+    c->s_ptab = k.take<int32_t>(2 * B * c->l_max_pages);
+    for (int bk = 0; bk < 2; ++bk) c->banks[bk].ptab = c->s_ptab ? c->s_ptab + (int64_t)bk * B * c->l_max_pages : nullptr;
+    {   // alias the current bank
+        const aur_ctx::Bank& K = c->banks[c->cur_bank];
+        c->d_x = K.d_x; c->s_ssq_mlp = K.s_ssq_mlp; c->s_ssq_attn = K.s_ssq_attn; c->d_logits = K.d_logits;
+        c->s_pos = K.s_pos; c->s_ids = K.s_ids; c->s_len = K.s_len; c->s_fin = K.s_fin; c->ptab_cur = K.ptab;
+    }
     return k.off;
 }
 
@@ -243,7 +268,9 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
 
 extern "C" void aur_destroy(aur_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->graph) hipGraphExecDestroy(ctx->graph);
+    ctx->banks[ctx->cur_bank].graph = ctx->graph;
+    for (auto& K : ctx->banks)
+        if (K.graph) hipGraphExecDestroy(K.graph);
     for (auto& kv : ctx->timers) {
         if (kv.second.e0) hipEventDestroy(kv.second.e0);
         if (kv.second.e1) hipEventDestroy(kv.second.e1);
@@ -358,9 +385,12 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
                 tab[(size_t)p * half + i] = make_float2(cosf(ang), sinf(ang));
             }
         CK(hipMemcpyAsync(ctx->l_rope, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, s));
-        std::vector<int32_t> pt((size_t)g.max_batch * ctx->l_max_pages);
+        std::vector<int32_t> pt((size_t)2 * g.max_batch * ctx->l_max_pages);
         for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;      // static allocation: slot b owns pages [b*max_pages, ...)
         CK(hipMemcpyAsync(ctx->s_ptab, pt.data(), pt.size() * 4, hipMemcpyHostToDevice, s));
+        // decode scratch in x-fragment form: lanes of unused batch rows must hold finite values forever
+        CK(hipMemsetAsync(ctx->d_attn, 0, (size_t)rup(g.max_batch, 16) * g.llm_hidden * 2, s));
+        CK(hipMemsetAsync(ctx->d_h, 0, (size_t)rup(g.max_batch, 16) * g.llm_mlp * 2, s));
         CK(hipStreamSynchronize(s));
     }
     if (!have_vit && !have_llm) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: no weights were provided");
@@ -699,7 +729,7 @@ extern "C" int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, c
 static KvLayout llm_kv(const aur_ctx* c, int layer) {
     KvLayout L;
     L.base = (half_t*)c->kvpool + (int64_t)layer * c->l_layer_halves;
-    L.page_table = c->s_ptab;
+    L.page_table = c->ptab_cur;
     L.max_pages = c->l_max_pages;
     L.page_tokens = c->cfg.page_tokens;
     L.heads = c->cfg.llm_heads;
@@ -730,11 +760,9 @@ extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_toke
     CK(hipMemsetAsync(ctx->s_pos, 0, (size_t)g.max_batch * 4, s));
     CK(hipMemsetAsync(ctx->s_ids, 0, (size_t)g.max_batch * g.max_new_tokens * 4, s));
     const size_t bp = (size_t)rup(g.max_batch, 16);       // unused fragment lanes must hold finite values
-    CK(hipMemsetAsync(ctx->d_x, 0, bp * g.llm_hidden * 2, s));
+    CK(hipMemsetAsync(ctx->d_x, 0, bp * g.llm_hidden * 2, s));          // bank-owned buffers only: the other bank may be decoding
     CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, 32 * 8, s));
     CK(hipMemsetAsync(ctx->s_ssq_attn, 0, 32 * 8, s));
-    CK(hipMemsetAsync(ctx->d_attn, 0, bp * g.llm_hidden * 2, s));
-    CK(hipMemsetAsync(ctx->d_h, 0, bp * g.llm_mlp * 2, s));
     return AUR_OK;
 }
 
@@ -1006,5 +1034,18 @@ extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, d
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *us_out = 1e3 * ms / iters;
+    return AUR_OK;
+}
+
+extern "C" int aur_select_bank(aur_ctx* ctx, int32_t bank) {
+    if (bank < 0 || bank >= ctx->nbanks) return aur_fail(ctx, AUR_ERR_ARG, "bank %d outside [0, %d) (aur_config.num_banks)", bank, ctx->nbanks);
+    if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_select_bank: workspace not set");
+    aur_ctx::Bank& o = ctx->banks[ctx->cur_bank];
+    o.batch = ctx->batch; o.max_new = ctx->max_new; o.eos = ctx->eos; o.graph = ctx->graph; o.graph_batch = ctx->graph_batch;
+    const aur_ctx::Bank& K = ctx->banks[bank];
+    ctx->cur_bank = bank;
+    ctx->d_x = K.d_x; ctx->s_ssq_mlp = K.s_ssq_mlp; ctx->s_ssq_attn = K.s_ssq_attn; ctx->d_logits = K.d_logits;
+    ctx->s_pos = K.s_pos; ctx->s_ids = K.s_ids; ctx->s_len = K.s_len; ctx->s_fin = K.s_fin; ctx->ptab_cur = K.ptab;
+    ctx->batch = K.batch; ctx->max_new = K.max_new; ctx->eos = K.eos; ctx->graph = K.graph; ctx->graph_batch = K.graph_batch;
     return AUR_OK;
 }

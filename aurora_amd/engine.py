@@ -37,7 +37,8 @@ def tokens_at_layer(t0: int, r: int, layer: int) -> int:
 
 class AuroraCapEngine:
     def __init__(self, cfg: dict, weights: dict, *, max_frames: int = 8, max_batch: int = 1, max_ctx: int = 4096,
-                 max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, device: str = "cuda:0"):
+                 max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, num_banks: int = 1,
+                 device: str = "cuda:0"):
         if not torch.cuda.is_available():
             raise _lib.AuroraHipError("AuroraCapEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback")
@@ -72,6 +73,9 @@ class AuroraCapEngine:
         c.llm_rms_eps, c.rope_theta, c.rope_factor = ll["rms_norm_eps"], ll["rope_theta"], ll.get("rope_factor", 1.0)
         c.max_frames, c.max_batch, c.max_ctx = max_frames, max_batch, max_ctx
         c.max_new_tokens, c.page_tokens, c.use_graph = max_new_tokens, page_tokens, int(use_graph)
+        c.num_banks = num_banks
+        self._bank_state = {0: (0, 0), 1: (0, 0)}        # bank -> (batch, max_new) for outputs()
+        self._bank = 0
         self.c = c
         self.v, self.l = v, l
         self.max_new_tokens = max_new_tokens
@@ -113,8 +117,9 @@ class AuroraCapEngine:
 
     def _stream(self):
         cur = torch.cuda.current_stream(self.dev)
-        if cur != self.stream:              # a caller switched streams: order ours after theirs
-            self.stream.wait_stream(cur)
+        if cur.cuda_stream != 0:            # any explicit stream the caller made current (e.g. a second pipeline stream)
+            return C.c_void_p(cur.cuda_stream)
+        self.stream.wait_stream(cur)        # null stream: order ours after it (it cannot be graph-captured)
         return C.c_void_p(self.stream.cuda_stream)
 
     def _h(self, t: torch.Tensor) -> torch.Tensor:
@@ -266,13 +271,10 @@ class AuroraCapEngine:
         assert nk.value == n_kept
         return out
 
-    def project_splice(self, vis: torch.Tensor, input_ids: Sequence[int], out: Optional[torch.Tensor] = None):
-        """vis [frames, n_kept, Dv] + ids (with -200 markers) -> (embeds [L_pad, d] fp16, seq_len).
-
-        Host builds the destination-row maps (model/utils.py:198-240 semantics: marker k takes frame k;
-        markers beyond the number of frames are dropped)."""
-        d = self.l["hidden_size"]
-        frames, n_kept = vis.shape[0], vis.shape[1]
+    def splice_plan(self, input_ids: Sequence[int], frames: int, n_kept: int):
+        """Destination-row maps of the prefix splice for one prompt (model/utils.py:198-240 semantics: marker k takes
+        frame k; markers beyond the number of frames are dropped), uploaded once.  Re-usable across calls: building it
+        involves blocking host->device copies, which must stay out of a multi-stream pipeline's steady state."""
         vis_rows, text_ids, text_rows = [], [], []
         row, k = 0, 0
         for tid in input_ids:
@@ -285,20 +287,35 @@ class AuroraCapEngine:
                 text_ids.append(int(tid))
                 text_rows.append(row)
                 row += 1
-        seq_len = row
-        used = len(vis_rows)
         vr = np.concatenate(vis_rows) if vis_rows else np.zeros(0, np.int64)
-        vflat = self._h(vis[:used]).reshape(used * n_kept, -1)
-        vr_t = torch.from_numpy(vr.astype(np.int32)).to(self.dev)
-        ti_t = torch.tensor(text_ids, dtype=torch.int32, device=self.dev)
-        tr_t = torch.tensor(text_rows, dtype=torch.int32, device=self.dev)
+        return dict(seq_len=row, used=len(vis_rows), n_kept=n_kept, ntext=len(text_ids),
+                    vis_rows=torch.from_numpy(vr.astype(np.int32)).to(self.dev),
+                    text_ids=torch.tensor(text_ids, dtype=torch.int32, device=self.dev),
+                    text_rows=torch.tensor(text_rows, dtype=torch.int32, device=self.dev))
+
+    def project_splice(self, vis: torch.Tensor, input_ids: Optional[Sequence[int]] = None, out: Optional[torch.Tensor] = None,
+                       plan: Optional[dict] = None):
+        """vis [frames, n_kept, Dv] + ids (with -200 markers) -> (embeds [L_pad, d] fp16, seq_len)."""
+        d = self.l["hidden_size"]
+        if plan is None:
+            plan = self.splice_plan(input_ids, vis.shape[0], vis.shape[1])
+        assert plan["n_kept"] == vis.shape[1] and plan["used"] <= vis.shape[0]
+        seq_len, used = plan["seq_len"], plan["used"]
+        vflat = self._h(vis[:used]).reshape(used * plan["n_kept"], -1)
         embeds = out if out is not None else torch.empty(_rup(seq_len, 32), d, dtype=torch.float16, device=self.dev)
         assert embeds.shape[0] >= _rup(seq_len, 32) and embeds.is_contiguous()
-        check(self.ctx, self.L.aur_project_splice(self.ctx, vflat.data_ptr(), vflat.shape[0], vr_t.data_ptr(), ti_t.data_ptr(),
-                                                  tr_t.data_ptr(), len(text_ids), seq_len, embeds.data_ptr(), self._stream()),
-              "aur_project_splice")
-        self._tmp = getattr(self, "_tmp", [])[-64:] + [(vflat, vr_t, ti_t, tr_t)]      # keep alive until consumed
+        check(self.ctx, self.L.aur_project_splice(self.ctx, vflat.data_ptr(), vflat.shape[0], plan["vis_rows"].data_ptr(),
+                                                  plan["text_ids"].data_ptr(), plan["text_rows"].data_ptr(), plan["ntext"], seq_len,
+                                                  embeds.data_ptr(), self._stream()), "aur_project_splice")
+        self._tmp = getattr(self, "_tmp", [])[-64:] + [(vflat, plan)]      # keep alive until consumed
         return embeds, seq_len
+
+    def select_bank(self, bank: int):
+        """Switch the generation bank (double-buffered KV slots / state) that the following calls act on."""
+        self._bank_state[self._bank] = (getattr(self, "_batch", 0), getattr(self, "_max_new", 0))
+        check(self.ctx, self.L.aur_select_bank(self.ctx, bank), "aur_select_bank")
+        self._bank = bank
+        self._batch, self._max_new = self._bank_state[bank]
 
     def begin_batch(self, batch: int, max_new_tokens: int, eos_id: Optional[int]):
         self._batch, self._max_new = batch, max_new_tokens

@@ -4,12 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
-  ViT-H/14-378 + per-layer ToMe over all frames -> projector + splice -> Llama-7B prefill per clip ->
-  batched greedy decode to exactly max_new_tokens (EOS disabled: random weights would make length arbitrary).
+  ViT-H/14-378 + per-layer ToMe over all frames -> projector + splice -> Llama-7B prefill (groups of equal-length
+  clips per pass) -> batched greedy decode to exactly max_new_tokens (EOS disabled: random weights would make the
+  length arbitrary).
 Workload = BASELINE.json configs[1]: AuroraCap-7B-VID, 8 frames, token_kept_ratio 0.3, 256 new tokens, 1 GPU.
 `value` = captions/sec of the whole job (all ranks), inputs resident in HBM when the timed region starts.
-For N > 1 clips shard across ranks (one process per GPU, no data-path collective); the only collective is the
-RCCL all_gather of the generated ids at the end of each step (the reference's gather_object, evaluator.py:519-546).
+
+By default the stages of a step run strictly one after another.  `--pipeline` software-pipelines steps on two HIP
+streams and two generation banks (KV slots + per-batch state): while batch i decodes (HBM-bound) the front end (ViT +
+prefill, MFMA-bound) of batch i+1 runs; the timed region then executes exactly K front ends and K decodes (the
+pipeline is primed during warm-up), i.e. the full work of K steps.  Measured gain on MI355X is only 2-3 % (the two
+kernel classes contend for CUs / LDS) at +37 % p50 TTFT, so it is opt-in.
+
+For N > 1 clips shard across ranks (one process per GPU, no data-path collective); the only collective is the RCCL
+all_gather of the generated ids at the end of each step (the reference's gather_object, evaluator.py:519-546).
 """
 import argparse
 import json
@@ -34,6 +42,10 @@ def parse():
     p.add_argument("--token_kept_ratio", type=float, default=0.3)
     p.add_argument("--max_new_tokens", type=int, default=256)
     p.add_argument("--prefill-group", type=int, default=8, help="clips prefetched per prefill pass (equal-length prompts)")
+    p.add_argument("--pipeline", action="store_true",
+                   help="overlap batch i's decode with batch i+1's ViT + prefill on two streams / two KV banks "
+                        "(measured on MI355X: +2-3 %% captions/s, +37 %% p50 TTFT - off by default)")
+    p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
@@ -77,10 +89,9 @@ def cpu_baseline(cfg, args, n_kept):
         pos += 1
     t_dec = (time.perf_counter() - t0) / ndec
     scale = l["num_hidden_layers"] / nl
-    t_lm_head = 0.0   # included in t_dec once per token (not scaled by layers): separate it
     t0 = time.perf_counter()
     torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
-    t_lm_head = time.perf_counter() - t0
+    t_lm_head = time.perf_counter() - t0          # once per token, not scaled by the layer count
     per_tok = (t_dec - t_lm_head) * scale + t_lm_head
     ttft = t_vit1 * args.num_frm + t_pre * scale
     total = ttft + per_tok * (args.max_new_tokens - 1)
@@ -102,8 +113,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    from aurora_amd import parallel
     from aurora_amd import synthetic as S
-    from aurora_amd.engine import AuroraCapEngine, _rup
+    from aurora_amd.engine import AuroraCapEngine, _rup, tokens_at_layer, tome_r
 
     if args.tiny:
         cfg = {"vit": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=4, intermediate_size=256, patch_size=14,
@@ -114,69 +126,122 @@ def main():
         cfg = S.AURORACAP_7B
     v, l = cfg["vit"], cfg["llm"]
     B, F, N = args.batch, args.num_frm, args.max_new_tokens
+    pipe = args.pipeline
     dev = f"cuda:{local}"
     weights = {"vit": S.vit_weights(v, device=dev), "projector": S.projector_weights(v["hidden_size"], l["hidden_size"], device=dev),
                "llm": S.llm_weights(l, device=dev)}
     t0tok = (v["image_size"] // v["patch_size"]) ** 2 + 1
-    from aurora_amd.engine import tokens_at_layer, tome_r
     r = tome_r(v["image_size"], v["image_size"], v["patch_size"], args.token_kept_ratio, v["num_hidden_layers"])
     n_kept = tokens_at_layer(t0tok, r, v["num_hidden_layers"] - 1) - 1
     L0 = 30 + F * n_kept
     max_ctx = _rup(L0 + N, 64)
     eng = AuroraCapEngine(cfg, weights, max_frames=B * F, max_batch=B, max_ctx=max_ctx, max_new_tokens=N,
-                          use_graph=not args.no_graph, device=dev)
+                          use_graph=not args.no_graph, num_banks=2 if pipe else 1, device=dev)
     del weights
     torch.cuda.empty_cache()
+    if args.gemm_mode >= 0:
+        eng.set_option("gemm_mode", args.gemm_mode)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B
     pixels = torch.cat([S.frames(F, clip0 + b, v["image_size"], device=dev) for b in range(B)], 0)     # [B*F, 3, H, W]
     ids = [S.prompt_ids(F, clip0 + b, 30, l["vocab_size"]) for b in range(B)]
+    G = max(1, min(args.prefill_group, B))
+    Mseq = _rup(L0, 32)
+    emb_all = torch.zeros(G * Mseq, l["hidden_size"], dtype=torch.float16, device=dev)
+    plans = [eng.splice_plan(ids[b], F, n_kept) for b in range(B)]   # static per prompt: uploaded once, outside the loop
     torch.cuda.synchronize()
-
-    emb_all = torch.zeros(max(1, min(args.prefill_group, B)) * _rup(L0, 32), l["hidden_size"], dtype=torch.float16, device=dev)
     ttft_ms = []
 
-    def step(record_ttft=False):
+    def front(bank, record_ttft=False):
+        """ViT + projector/splice + prefill of one batch into generation bank `bank` (enqueue only)."""
+        eng.select_bank(bank)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
         vis = eng.vit_encode(pixels, r)                            # [B*F, n_kept, Dv]
         eng.begin_batch(B, N, None)
         evs = []
-        G = max(1, min(args.prefill_group, B))
-        Mseq = _rup(L0, 32)
         for b0 in range(0, B, G):                                  # equal-length prompts: G clips per prefill pass
             n = min(G, B - b0)
             for j in range(n):
-                _, L = eng.project_splice(vis[(b0 + j) * F:(b0 + j + 1) * F], ids[b0 + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+                _, L = eng.project_splice(vis[(b0 + j) * F:(b0 + j + 1) * F], plan=plans[b0 + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
                 assert L == L0
             eng.prefill_batch(b0, n, emb_all, L0)
             if record_ttft:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 evs.extend([e] * n)
+        return ev0, evs
+
+    def back(bank):
+        """Decode of the batch in `bank`, result copy (synchronises the decode stream) and the cross-rank gather."""
+        eng.select_bank(bank)
         eng.decode(N - 1)
-        out = eng.outputs()                                        # synchronises
-        if world > 1:                                              # result gather over RCCL / xGMI
-            from aurora_amd import parallel
-            parallel.gather_results(out, N, B, dev)
-        if record_ttft:
-            ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+        out = eng.outputs()
+        if world > 1:
+            parallel.gather_results(out, N, B, dev)                # RCCL all_gather over xGMI
         return out
 
-    for _ in range(args.warmup):
-        step()
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(record_ttft=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
+    out = None
+    if not pipe:
+        def step(record_ttft=False):
+            ev0, evs = front(0, record_ttft)
+            o = back(0)
+            if record_ttft:
+                ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+            return o
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(True)
+        fence()
+        elapsed = time.perf_counter() - t_start
+    else:
+        sD = torch.cuda.current_stream()                           # the engine's stream: decode
+        sP = torch.cuda.Stream()                                   # front end of the next batch
+        sP.wait_stream(sD)
+        ev_front = [None, None]
+        ev_back = [None, None]
+        pending = []
+
+        def iteration(i, record_ttft):
+            bank = i & 1
+            with torch.cuda.stream(sP):                            # front end of batch i+1 into the other bank
+                if ev_back[bank ^ 1] is not None:
+                    sP.wait_event(ev_back[bank ^ 1])               # its previous occupant must have finished decoding
+                ev0, evs = front(bank ^ 1, record_ttft)
+                ev_front[bank ^ 1] = torch.cuda.Event()
+                ev_front[bank ^ 1].record(sP)
+                if record_ttft:
+                    pending.append((ev0, evs))
+            sD.wait_event(ev_front[bank])                          # batch i was prefetched one iteration ago
+            o = back(bank)
+            ev_back[bank] = torch.cuda.Event()
+            ev_back[bank].record(sD)
+            return o
+
+        with torch.cuda.stream(sP):                                # prime: front end of batch 0
+            front(0)
+            ev_front[0] = torch.cuda.Event()
+            ev_front[0].record(sP)
+        for i in range(args.warmup):
+            iteration(i, False)
+        fence()
+        t_start = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):     # K front ends + K decodes
+            out = iteration(i, True)
+        fence()
+        elapsed = time.perf_counter() - t_start
+        for ev0, evs in pending:
+            ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+        eng.select_bank(0)
     assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -196,22 +261,28 @@ def main():
                                     % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
                        "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
                        "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
-                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": max(1, min(args.prefill_group, B))},
+                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G,
+                       "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
-            "ttft_note": "time from step start to each clip's first token inside a batch of %d clips (ViT for all clips runs first)" % B,
+            "ttft_note": "time from the start of a batch's front end (ViT for all its clips first) to each clip's first token, batch of %d clips"
+                         % B + ("; the front end shares the GPU with the previous batch's decode" if pipe else ""),
         }
 
-    # ---- instrumented pass (rank 0, after the timed region): HIP events per stage and around the dominant kernel
+    # ---- instrumented pass (rank 0, after the timed region, not pipelined): HIP events per stage and around the
+    #      two HBM-bound decode kernels
     if rank == 0 and not args.no_instrument:
+        torch.cuda.synchronize()
+        eng.select_bank(0)
         eng.profile(True)
-        step()
+        front(0)
+        back(0)
         stages = {k: eng.profile_read(k)[0] for k in ("vit", "project", "prefill", "decode")}
         ams, an = eng.profile_read("decode_attn")
         kms, kn = eng.profile_read("decode_gemm_gateup")
         eng.profile(False)
         result["stage_ms_instrumented_step"] = stages
-        d, mlp, H = l["hidden_size"], l["intermediate_size"], l["num_attention_heads"]
-        how = "HIP events around every launch of this kernel in one extra eager step on the launch stream (after the timed steps)"
+        d, mlp = l["hidden_size"], l["intermediate_size"]
+        how = "HIP events around every launch of this kernel in one extra eager, un-pipelined step on the launch stream (after the timed steps)"
         pmc = {}
         try:                                                       # rocprofv3 --pmc summary of this same command, if committed
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -219,8 +290,8 @@ def main():
             pass
         roof = {}
         if an > 0:
-            # decode attention: K + V of every cached token of every sequence, all heads, read once per layer-step.
-            # context of a sequence at decode step s (1..N-1) is L0 + s keys -> mean over the N-1 steps of one generation
+            # decode attention: K + V of every cached token of every sequence, all heads, read once per layer-step; the
+            # context of a sequence at decode step s (1..N-1) is L0 + s keys -> mean over one generation
             mean_ctx = L0 + N / 2.0
             alg = B * mean_ctx * 2 * d * 2                               # K + V bytes (q and the split partials are < 0.1 %)
             avg_s = ams / an * 1e-3
@@ -240,13 +311,12 @@ def main():
                                      "traffic": pmc["skinny_kernel_gateup"]["bytes_per_launch"] if "skinny_kernel_gateup" in pmc else None,
                                      "algorithmic_bytes_per_launch": alg,
                                      "avg_launch_us": avg_s * 1e6, "launches_timed": kn, "how": how}
-        # the dominant kernel = the one with the larger total time in the decode loop
-        if roof:
+        if roof:    # the dominant kernel = the one with the larger total time in the decode loop
             dom = max(roof, key=lambda k: roof[k]["avg_launch_us"] * roof[k]["launches_timed"])
             result["roofline"] = roof[dom]
-            for k, v in roof.items():
+            for k, val in roof.items():
                 if k != dom:
-                    result["roofline_" + k] = v
+                    result["roofline_" + k] = val
         # single-clip latency (batch 1): TTFT without queueing behind other clips' ViT/prefill
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -52,6 +52,7 @@ typedef struct aur_config {
     int32_t max_new_tokens;     /* output buffer width per slot */
     int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
     int32_t use_graph;          /* 1: capture the decode step into a hipGraph */
+    int32_t num_banks;          /* 1 or 2 generation banks (2: KV pool and per-batch state doubled, see aur_select_bank) */
 } aur_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -103,6 +104,11 @@ int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, const int32_
 /* Greedy generation state: replaces llm.generate(inputs_embeds=..., do_sample=False, max_new_tokens=N)
  * (inference.py:89-96).  eos_id < 0 disables the EOS stop (benchmark: fixed-length outputs). */
 int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t eos_id, void* stream);
+/* Generation banks (num_banks = 2): each bank has its own max_batch KV slots, residual stream, outputs and captured
+ * graph.  All generation calls (begin_batch / prefill / decode / get_outputs / ...) act on the selected bank, so batch
+ * i can decode on one stream while batch i+1 is prefetched into the other bank on a second stream (decode is HBM-bound,
+ * ViT + prefill are MFMA-bound).  The caller orders the streams with its own events. */
+int aur_select_bank(aur_ctx* ctx, int32_t bank);
 /* Prefill `slot` with embeds [round_up(seq_len,32), llm_hidden] (clobbered), write its KV pages, produce the
  * first token (argmax of the last position's logits). */
 int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream);

@@ -8,6 +8,57 @@ from tests.test_gpu_llm import LLM_CFGS, make_engine, padded
 pytestmark = pytest.mark.gpu
 
 
+def test_two_banks_overlapped_streams_equal_sequential():
+    """Generation banks: batch A decodes on one stream while batch B is prefetched into the other bank on a second
+    stream; both must produce exactly what they produce when run alone, one after the other."""
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.util import rand_llm_weights
+    cfg = LLM_CFGS["hd64"]
+    w = rand_llm_weights(cfg, 14)
+    gen = torch.Generator().manual_seed(41)
+    A = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in (200, 200, 200)]
+    Bq = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in (333, 333, 333)]
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=3, max_ctx=512, max_new_tokens=40,
+                          num_banks=2)
+    try:
+        def big(xs):
+            return torch.cat([padded(e) for e in xs], 0).contiguous()
+        ref = {}
+        for name, xs in (("A", A), ("B", Bq)):                      # sequential reference, bank 0
+            eng.select_bank(0)
+            eng.begin_batch(3, 40, None)
+            eng.prefill_batch(0, 3, big(xs), xs[0].shape[0])
+            eng.decode(39)
+            ref[name] = eng.outputs()
+        for rep in range(3):                                         # overlapped: A decodes in bank 0 || B front end in bank 1
+            sD = torch.cuda.current_stream()
+            sP = torch.cuda.Stream()
+            sP.wait_stream(sD)
+            eng.select_bank(0)
+            eng.begin_batch(3, 40, None)
+            eng.prefill_batch(0, 3, big(A), 200)
+            with torch.cuda.stream(sP):
+                eng.select_bank(1)
+                eng.begin_batch(3, 40, None)
+                bb = big(Bq)
+                eng.prefill_batch(0, 3, bb, 333)
+                evp = torch.cuda.Event()
+                evp.record(sP)
+            eng.select_bank(0)
+            eng.decode(39)
+            outA = eng.outputs()
+            sD.wait_event(evp)
+            eng.select_bank(1)
+            eng.decode(39)
+            outB = eng.outputs()
+            assert outA == ref["A"] and outB == ref["B"], rep
+        with pytest.raises(Exception):
+            eng.select_bank(2)
+    finally:
+        eng.select_bank(0)
+        eng.close()
+
+
 def test_batch_of_20_two_column_groups_equals_single():
     """More than 16 slots use two MFMA column groups in the decode GEMVs; every slot must still generate exactly
     what it generates alone (batch-invariant arithmetic), including ragged prompt lengths."""
