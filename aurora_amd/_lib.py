@@ -72,6 +72,10 @@ SIGNATURES = {
     "aur_microbench": (C.c_int, [_P, C.c_char_p, _I, C.POINTER(C.c_double), _P]),
     "aur_profile_enable": (C.c_int, [_P, _I]),
     "aur_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "aur_preprocess_plan_len": (_L, [_I, _I, _I]),
+    "aur_preprocess_plan": (C.c_int, [_I, _I, _I, _P, _L]),
+    "aur_preprocess_tmp_bytes": (_L, [_I, _I, _I, _I]),
+    "aur_preprocess_frames": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -14,10 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libaurora_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "norm.hip", "tome.hip", "vit.hip", "decode.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "norm.hip", "tome.hip", "vit.hip", "decode.hip", "preprocess.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # tome.hip carries the bit-exact fp32 contract: no implicit FMA contraction
-PER_FILE = {"tome.hip": ["-ffp-contract=off"]}
+# preprocess.hip computes Pillow's resampling taps in doubles on the host: same rule
+PER_FILE = {"tome.hip": ["-ffp-contract=off"], "preprocess.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -168,6 +168,24 @@ int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, double* us_o
 int aur_profile_enable(aur_ctx* ctx, int32_t on);
 int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out, int64_t* launches_out);
 
+/* ---- input stage (stateless, no ctx) --------------------------------- */
+/* Replaces CLIPImageProcessor(size=378, crop_size=378)(frames)["pixel_values"].to(float16) at inference.py:58-63,
+ * 71-75 (Pillow 8-bit BICUBIC resize of the shortest edge to `image`, centre crop, rescale, normalise) for decoded
+ * rgb24 frames that are already on the device.  Bit-exact against the reference processor.
+ *
+ * aur_preprocess_plan: HOST-only; fills `plan_host` (aur_preprocess_plan_len int32 words: geometry header, per output
+ * column / row the first input index, tap count and int32 taps with 22 fractional bits) for one input size.  The
+ * caller copies it to the device once per input size and reuses it.
+ * aur_preprocess_frames: frames_dev uint8 [frames, in_h, in_w, 3]; lut_dev fp16 bits [3][256] =
+ * ((v * rescale) - mean[c]) / std[c] computed by the caller from preprocessor_config.json; tmp_dev
+ * aur_preprocess_tmp_bytes; out_pixels fp16 [frames, 3, image, image] (the layout aur_vit_encode takes). */
+int64_t aur_preprocess_plan_len(int32_t in_h, int32_t in_w, int32_t image);
+int aur_preprocess_plan(int32_t in_h, int32_t in_w, int32_t image, int32_t* plan_host, int64_t len);
+int64_t aur_preprocess_tmp_bytes(int32_t frames, int32_t in_h, int32_t in_w, int32_t image);
+int aur_preprocess_frames(const uint8_t* frames_dev, int32_t frames, int32_t in_h, int32_t in_w, int32_t image,
+                          const int32_t* plan_dev, const uint16_t* lut_dev, uint8_t* tmp_dev, void* out_pixels,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,8 +5,8 @@
     python inference.py --model_path <xtuner-format dir> --visual_input clip.mp4 --num_frm 8 \
         --token_kept_ratio 0.3 --max_new_tokens 256
 
-Host-side preprocessing (tokenizer, CLIP image processor, PyAV frame sampling) uses the same third-party
-packages the reference uses; the three hot stages run in libaurora_hip.so.
+Tokenizer and PyAV frame decoding use the same third-party packages the reference uses; resize / crop / normalise
+(bit-identical to the reference's CLIPImageProcessor call) and the three hot stages run in libaurora_hip.so.
 `--synthetic` replaces checkpoint, tokenizer and video by the seeded synthetic clip of SURVEY 8d (prints ids).
 """
 import argparse
@@ -18,31 +18,27 @@ import torch
 
 
 def read_video_pyav(path: str, num_frm: int = 8):
-    """Uniform frame sampling, src/xtuner/xtuner/tools/load_video.py:31-71 semantics:
-    indices = linspace(0, total-1, num_frm, dtype=int); the last frame is appended when missing."""
+    """Uniform frame sampling with the contract of src/xtuner/xtuner/tools/load_video.py:31-71
+    (aurora_amd.preprocess.sample_frame_indices: linspace over min(total, num_frm) frames + the last frame);
+    webm / mkv and streams without a frame count are decoded packet by packet first, as the reference does."""
+    from aurora_amd.preprocess import sample_frame_indices
     try:
         import av
     except ImportError as e:
         raise RuntimeError("PyAV (`av`) is required to decode video input") from e
     container = av.open(path)
-    total = container.streams.video[0].frames
-    if total <= 0:                                   # webm / mkv: count by decoding packets (load_video.py fallback)
+    total = 0 if ("webm" in path or "mkv" in path) else container.streams.video[0].frames
+    if total <= 0:
         frames = [f for f in container.decode(video=0)]
-        total = len(frames)
-        idx = np.linspace(0, total - 1, num_frm, dtype=int).tolist()
-        if total - 1 not in idx:
-            idx.append(total - 1)
-        return np.stack([frames[i].to_ndarray(format="rgb24") for i in idx])
-    idx = set(np.linspace(0, total - 1, num_frm, dtype=int).tolist())
-    idx.add(total - 1)
-    out = []
-    container.seek(0)
+        return np.stack([frames[i].to_ndarray(format="rgb24") for i in sample_frame_indices(len(frames), num_frm)])
+    idx = sample_frame_indices(total, num_frm)
+    want, out = set(idx), {}
     for i, frame in enumerate(container.decode(video=0)):
-        if i in idx:
-            out.append(frame.to_ndarray(format="rgb24"))
-        if i > max(idx):
+        if i in want:
+            out[i] = frame.to_ndarray(format="rgb24")
+        if i >= idx[-1]:
             break
-    return np.stack(out)
+    return np.stack([out[i] for i in idx if i in out])
 
 
 def main():
@@ -56,6 +52,7 @@ def main():
     parser.add_argument('--top_p', type=float, help='top p', default=1.0)
     parser.add_argument('--num_beams', type=int, help='number of beams', default=1)
     parser.add_argument('--max_new_tokens', type=int, help='max new tokens', default=2048)
+    parser.add_argument('--host_preprocess', action='store_true', help='resize/normalise on the host with CLIPImageProcessor (PIL) instead of the HIP input stage')
     parser.add_argument('--synthetic', action='store_true', help='seeded synthetic weights / clip / prompt ids (no checkpoint needed)')
     args = parser.parse_args()
     if args.num_beams != 1:
@@ -81,18 +78,27 @@ def main():
         max_ctx = 128 + args.num_frm * 729 + args.max_new_tokens
         model = AuroraModel.from_pretrained(args.model_path, max_frames=max(args.num_frm + 1, 2), max_ctx=max_ctx,
                                             max_new_tokens=args.max_new_tokens)
-        image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=378, crop_size=378)
+        if args.host_preprocess:      # the reference's host path (PIL); default is the bit-identical HIP input stage
+            image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=378, crop_size=378)
+
+            def to_pixels(frames):
+                return image_processor(list(frames), return_tensors='pt')['pixel_values'].to(dtype=torch.float16)
+        else:
+            from aurora_amd.preprocess import FramePreprocessor
+            gpu_pre = FramePreprocessor(image=378)
+
+            def to_pixels(frames):
+                return gpu_pre(torch.from_numpy(np.ascontiguousarray(np.stack(list(frames)))).cuda())
         tokenizer = AutoTokenizer.from_pretrained(args.model_path, trust_remote_code=True, padding_side='right')
         data = dict()
         if args.visual_input.endswith('mp4'):
             video_frames = read_video_pyav(args.visual_input, args.num_frm)
-            image_tensor = image_processor(list(video_frames), return_tensors='pt')['pixel_values']
-            data["pixel_values"] = image_tensor.to(dtype=torch.float16).unsqueeze(0)
+            data["pixel_values"] = to_pixels(video_frames).unsqueeze(0)
             n_img = len(video_frames)
         elif args.visual_input.endswith('png') or args.visual_input.endswith('jpg'):
             from PIL import Image
-            image = Image.open(args.visual_input)
-            data["pixel_values"] = image_processor(image, return_tensors='pt')['pixel_values'].to(dtype=torch.float16)
+            image = np.asarray(Image.open(args.visual_input).convert("RGB"))       # the processor's do_convert_rgb
+            data["pixel_values"] = to_pixels([image])
             n_img = 1
         else:
             sys.exit("error: --visual_input must end with mp4, png or jpg")

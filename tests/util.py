@@ -88,6 +88,35 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+# ---- input stage (g10_preprocess.npz): name -> (H, W, recipe, seed); rows stored in full in the fixture
+PREPROCESS_CASES = {
+    "vga_noise": (480, 640, "noise", 1),
+    "hd_edges": (720, 1280, "edges", 2),
+    "portrait_noise": (640, 480, "noise", 3),
+    "square_same": (378, 378, "noise", 4),
+    "upscale_smooth": (200, 300, "smooth", 5),
+    "tiny_odd": (97, 131, "noise", 6),
+    "fullhd_smooth": (1080, 1920, "smooth", 7),
+    "near_square": (379, 377, "edges", 8),
+    "tall_same_w": (1000, 378, "noise", 9),
+}
+PREPROCESS_ROWS = [0, 1, 100, 188, 376, 377]
+
+
+def preprocess_case_input(h, w, kind, seed):
+    """Deterministic rgb24 test frame [h, w, 3] uint8 (sha256 recorded in the fixture guards against RNG drift)."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind == "edges":                       # saturated blocks: exercises the negative bicubic lobes + clipping
+        by, bx = rng.integers(3, 40), rng.integers(3, 40)
+        yy, xx = np.arange(h)[:, None] // by, np.arange(w)[None, :] // bx
+        base = (((yy + xx) % 2) * 255).astype(np.uint8)
+        return np.stack([base, 255 - base, np.where(rng.integers(0, 2, (h, w)) > 0, base, 255 - base).astype(np.uint8)], -1)
+    y, x = np.mgrid[0:h, 0:w].astype(np.int64)
+    return np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x * 7 + y * 13) % 256)], -1).astype(np.uint8)
+
+
 def to_match(idx: dict, device="cpu"):
     """GPU index dict (int32 tensors) -> oracle match dict (int64, CPU)."""
     return dict(r=idx["r"], unm_idx=idx["unm_idx"].long().to(device), src_idx=idx["src_idx"].long().to(device),
