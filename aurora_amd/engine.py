@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -79,6 +79,7 @@ class AuroraCapEngine:
         self.c = c
         self.v, self.l = v, l
         self.max_new_tokens = max_new_tokens
+        self.max_batch = max_batch
         self.ctx = C.c_void_p()
         rc = self.L.aur_create(C.byref(c), C.byref(self.ctx))
         if rc != 0:
@@ -374,6 +375,43 @@ class AuroraCapEngine:
         vis = self.vit_encode(pixels, r)
         emb, L = self.project_splice(vis, input_ids)
         return self.generate([emb], [L], max_new_tokens, eos_id)[0]
+
+    def caption_batch(self, clips: Sequence[Tuple[torch.Tensor, Sequence[int]]], token_kept_ratio: float, max_new_tokens: int,
+                      eos_id: Optional[int] = 2, prefill_group: int = 8, check_every: int = 32) -> List[List[int]]:
+        """Whole path for up to max_batch clips at once: (pixel_values [f, C, H, W], input_ids with -200 markers) each.
+        Clips may differ in frame count and prompt; neighbours whose spliced length is equal share one prefill pass.
+        Every kernel on the path is batch-invariant, so each clip gets exactly the ids it gets when captioned alone."""
+        B = len(clips)
+        if not 1 <= B <= self.max_batch:
+            raise ValueError(f"{B} clips for an engine built with max_batch={self.max_batch}")
+        d = self.l["hidden_size"]
+        rs, plans = [], []
+        for px, ids in clips:
+            r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
+            t0 = (self.v["image_size"] // self.v["patch_size"]) ** 2 + 1
+            rs.append(r)
+            plans.append(self.splice_plan(ids, px.shape[0], tokens_at_layer(t0, r, self.v["num_hidden_layers"] - 1) - 1))
+        self.begin_batch(B, max_new_tokens, eos_id)
+        b = 0
+        while b < B:
+            L, g = plans[b]["seq_len"], 1
+            while b + g < B and g < prefill_group and plans[b + g]["seq_len"] == L:
+                g += 1
+            Lp = _rup(L, 32)
+            buf = torch.empty(g * Lp, d, dtype=torch.float16, device=self.dev)
+            for i in range(g):
+                vis = self.vit_encode(clips[b + i][0], rs[b + i])
+                self.project_splice(vis, out=buf[i * Lp:(i + 1) * Lp], plan=plans[b + i])
+            self.prefill_batch(b, g, buf, L)
+            b += g
+        done = 1
+        while done < max_new_tokens:
+            n = min(check_every, max_new_tokens - done) if eos_id is not None else max_new_tokens - done
+            self.decode(n)
+            done += n
+            if eos_id is not None and self.unfinished() == 0:
+                break
+        return self.outputs()
 
     # ------------------------------------------------------------------ kernel-level entry points (tests)
     def tome_step(self, metric: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], r: int):

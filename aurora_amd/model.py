@@ -88,11 +88,26 @@ class AuroraModel:
         self.llm = _LLM(engine, eos_token_id)
 
     @classmethod
-    def from_pretrained(cls, path: str, *, max_frames: int = 16, max_ctx: int = 8192, max_new_tokens: int = 2048, **kw):
+    def from_pretrained(cls, path: str, *, max_frames: int = 16, max_ctx: int = 8192, max_new_tokens: int = 2048,
+                        max_batch: int = 1, **kw):
         from .checkpoint import load_auroracap
         cfg, weights = load_auroracap(path)
-        eng = AuroraCapEngine(cfg, weights, max_frames=max_frames, max_batch=1, max_ctx=max_ctx, max_new_tokens=max_new_tokens, **kw)
+        eng = AuroraCapEngine(cfg, weights, max_frames=max_frames, max_batch=max_batch, max_ctx=max_ctx,
+                              max_new_tokens=max_new_tokens, **kw)
         return cls(eng, cfg["llm"].get("eos_token_id", 2))
+
+    def caption_batch(self, clips, max_new_tokens: int = 2048, eos_token_id="default"):
+        """Several clips through the three calls at once (what a harness gets by looping inference.py:87-96 over its
+        requests): clips = [(pixel_values [f, c, h, w], input_ids with -200 markers), ...] -> list of new-token id lists,
+        identical per clip to the one-at-a-time calls.  Uses visual_encoder.visual_token_merge_ratio."""
+        eos = self.llm.eos_token_id if eos_token_id == "default" else eos_token_id
+        out = []
+        B = self.engine.max_batch
+        n = min(max_new_tokens, self.engine.max_new_tokens)
+        for c0 in range(0, len(clips), B):
+            group = [(px, ids.tolist() if torch.is_tensor(ids) else list(ids)) for px, ids in clips[c0:c0 + B]]
+            out.extend(self.engine.caption_batch(group, self.visual_encoder.visual_token_merge_ratio, n, eos))
+        return out
 
     def __call__(self, data: dict, data_samples=None, mode: str = "loss"):
         return self.forward(data, data_samples, mode)

@@ -17,28 +17,7 @@ import numpy as np
 import torch
 
 
-def read_video_pyav(path: str, num_frm: int = 8):
-    """Uniform frame sampling with the contract of src/xtuner/xtuner/tools/load_video.py:31-71
-    (aurora_amd.preprocess.sample_frame_indices: linspace over min(total, num_frm) frames + the last frame);
-    webm / mkv and streams without a frame count are decoded packet by packet first, as the reference does."""
-    from aurora_amd.preprocess import sample_frame_indices
-    try:
-        import av
-    except ImportError as e:
-        raise RuntimeError("PyAV (`av`) is required to decode video input") from e
-    container = av.open(path)
-    total = 0 if ("webm" in path or "mkv" in path) else container.streams.video[0].frames
-    if total <= 0:
-        frames = [f for f in container.decode(video=0)]
-        return np.stack([frames[i].to_ndarray(format="rgb24") for i in sample_frame_indices(len(frames), num_frm)])
-    idx = sample_frame_indices(total, num_frm)
-    want, out = set(idx), {}
-    for i, frame in enumerate(container.decode(video=0)):
-        if i in want:
-            out[i] = frame.to_ndarray(format="rgb24")
-        if i >= idx[-1]:
-            break
-    return np.stack([out[i] for i in idx if i in out])
+from aurora_amd.preprocess import read_video_pyav  # noqa: E402  (frame sampling contract of load_video.py:31-71)
 
 
 def main():

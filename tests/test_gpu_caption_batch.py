@@ -1,0 +1,97 @@
+"""GPU: several ragged clips through the whole path at once (AuroraCapEngine.caption_batch / AuroraModel.caption_batch /
+the lmms-eval adaptor) must give every clip exactly the ids it gets when captioned alone."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_llm import LLM_CFGS
+from tests.util import rand_llm_weights, rand_proj_weights, rand_vit_weights
+
+pytestmark = pytest.mark.gpu
+
+VCFG = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=4, intermediate_size=128, patch_size=14,
+            image_size=56, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+
+
+def build(max_batch, max_new=16):
+    from aurora_amd.engine import AuroraCapEngine
+    lcfg = LLM_CFGS["hd32"]
+    w = {"vit": rand_vit_weights(VCFG, 1), "projector": rand_proj_weights(64, lcfg["hidden_size"], 2), "llm": rand_llm_weights(lcfg, 3)}
+    return AuroraCapEngine({"vit": VCFG, "llm": lcfg}, w, max_frames=4, max_batch=max_batch, max_ctx=512, max_new_tokens=max_new)
+
+
+def clips(n, seed):
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        f = 1 + (i * 2) % 4 if i % 3 else 3                       # runs of equal shapes (shared prefill) and ragged ones
+        px = torch.randn(f, 3, 56, 56, generator=gen).half()
+        ids = [1, 17 + i % 2] + [-200, 30] * f + [40, 41][: 1 + i % 2]
+        out.append((px, ids))
+    return out
+
+
+def test_engine_caption_batch_equals_single():
+    eng = build(max_batch=6)
+    try:
+        cs = clips(6, 3)
+        together = eng.caption_batch(cs, 0.5, 12, eos_id=None)
+        grouped2 = eng.caption_batch(cs, 0.5, 12, eos_id=None, prefill_group=1)
+        assert together == grouped2
+        for b, (px, ids) in enumerate(cs):
+            assert together[b] == eng.caption_ids(px, ids, 0.5, 12, eos_id=None), b
+        with pytest.raises(ValueError):
+            eng.caption_batch(clips(7, 4), 0.5, 4, eos_id=None)
+        # EOS handling: slots stop independently
+        eos = together[1][3]
+        with_eos = eng.caption_batch(cs, 0.5, 12, eos_id=eos)
+        for b in range(6):
+            want = together[b][: together[b].index(eos) + 1] if eos in together[b] else together[b]
+            assert with_eos[b] == want, b
+    finally:
+        eng.close()
+
+
+def test_model_caption_batch_chunks_over_max_batch():
+    from aurora_amd.model import AuroraModel
+    eng = build(max_batch=3)
+    try:
+        m = AuroraModel(eng, eos_token_id=None)
+        m.visual_encoder.reset_tome_r(0.5)
+        cs = clips(7, 5)                                            # 7 clips on a 3-slot engine: 3 + 3 + 1
+        out = m.caption_batch([(px, torch.tensor(ids)) for px, ids in cs], max_new_tokens=8)
+        assert len(out) == 7
+        for b, (px, ids) in enumerate(cs):
+            assert out[b] == eng.caption_ids(px, ids, 0.5, 8, eos_id=None), b
+    finally:
+        eng.close()
+
+
+def test_lmms_adaptor_on_real_engine():
+    """generate_until of the adaptor: HIP input stage + caption_batch on a real engine (character-level fake tokenizer)."""
+    from aurora_amd.lmms_plugin.models import auroracap_mi355x as P
+    from aurora_amd.model import AuroraModel
+    from aurora_amd.preprocess import FramePreprocessor
+    from tests.test_lmms_plugin import FakeTok
+    eng = build(max_batch=4, max_new=8)
+    try:
+        m = AuroraModel(eng, eos_token_id=None)
+        pre = FramePreprocessor(image=56)
+        ad = P.AuroraCapMI355X(pretrained="unused", device="cuda", batch_size=4, token_merge_ratio=0.5, _model=m, _tokenizer=FakeTok(),
+                               _preprocessor=pre)
+        rng = np.random.default_rng(2)
+        docs = {i: rng.integers(0, 256, (1 + i % 3, 70 + 10 * (i % 2), 90, 3), dtype=np.uint8) for i in range(6)}
+        ad.task_dict = {"vdc": {"test": docs}}
+        ctxs = ["describe " + "x" * i for i in range(6)]
+        reqs = [SimpleNamespace(args=(ctxs[i], {"max_new_tokens": 8}, lambda d: [d], i, "vdc", "test")) for i in range(6)]
+        texts = ad.generate_until(reqs)
+        tok = FakeTok()
+        for i in range(6):                                          # each request alone through the engine
+            px = pre(torch.from_numpy(docs[i]).cuda())
+            ids = P.tokenizer_image_token(P.conv_prompt(P.question_with_image_tokens(ctxs[i], len(docs[i]))), tok)
+            want = eng.caption_ids(px, ids, 0.5, 8, eos_id=None)
+            assert texts[i] == " ".join(map(str, want)), i
+    finally:
+        eng.close()

@@ -1,0 +1,135 @@
+"""CPU: host logic of the lmms-eval adaptor with injected fakes for model / tokenizer /
+preprocessor - prompt construction, llava tokenizer_image_token semantics, batching order, generation defaults,
+plugin-loader contract.  The engine itself is covered by the GPU suites."""
+import importlib
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from aurora_amd.lmms_plugin.models import auroracap_mi355x as P
+
+
+class FakeTok:
+    bos_token_id, eos_token_id, pad_token_id = 1, 2, None
+
+    def _ids(self, s):
+        return [10 + (ord(c) % 50) for c in s]
+
+    def __call__(self, s):
+        return SimpleNamespace(input_ids=[self.bos_token_id] + self._ids(s))
+
+    def encode(self, s, add_special_tokens=False):
+        return ([self.bos_token_id] if add_special_tokens else []) + self._ids(s)
+
+    def decode(self, ids):
+        return " ".join(map(str, ids))
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(map(str, x)) for x in ids]
+
+
+class FakeModel:
+    def __init__(self):
+        self.visual_encoder = SimpleNamespace(ratio=None, reset_tome_r=lambda r: setattr(self.visual_encoder, "ratio", r))
+        self.calls = []
+
+    def caption_batch(self, clips, max_new_tokens=2048):
+        self.calls.append((len(clips), max_new_tokens))
+        return [[int(px.shape[0]), len(ids), sum(1 for t in ids if t == -200)] for px, ids in clips]
+
+
+def fake_pre(frames):
+    return torch.zeros(frames.shape[0], 3, 4, 4, dtype=torch.float16)
+
+
+def make(batch_size=4, **kw):
+    return P.AuroraCapMI355X(pretrained="unused", device="cpu", batch_size=batch_size, _model=FakeModel(), _tokenizer=FakeTok(),
+                             _preprocessor=fake_pre, **kw)
+
+
+def test_reference_defaults_and_surface():
+    m = make()
+    assert (m.token_merge_ratio, m.max_frames_num, m.conv_template, m.resolution) == (0.4, 16, "vicuna_v1", 378)   # auroracap.py:56-62
+    assert m.batch_size == 4 and m.rank == 0 and m.world_size == 1 and m.eot_token_id == 2
+    with pytest.raises(AssertionError):
+        make(bogus=1)
+    with pytest.raises(NotImplementedError):
+        make(slowfast=True)
+    with pytest.raises(NotImplementedError):
+        m.loglikelihood([])
+
+
+def test_vicuna_v1_prompt_and_image_tokens():
+    q = P.question_with_image_tokens("Describe the video in detail.", 3)
+    assert q == "<image> <image> <image>\nDescribe the video in detail."
+    assert P.question_with_image_tokens("<image>\nalready there", 3) == "<image>\nalready there"
+    assert P.question_with_image_tokens("no visuals", 0) == "no visuals"
+    p = P.conv_prompt(q)
+    assert p == ("A chat between a curious human and an artificial intelligence assistant. The assistant gives helpful, "
+                 "detailed, and polite answers to the human's questions. USER: <image> <image> <image>\n"
+                 "Describe the video in detail. ASSISTANT:")
+    with pytest.raises(NotImplementedError):
+        P.conv_prompt(q, "llava_llama_3")
+
+
+def test_tokenizer_image_token_llava_semantics():
+    tok = FakeTok()
+    ids = P.tokenizer_image_token("ab<image> <image>cd", tok)
+    # one BOS kept, per-chunk BOS stripped, -200 between chunks
+    assert ids == [1] + tok._ids("ab") + [-200] + tok._ids(" ") + [-200] + tok._ids("cd")
+    assert P.tokenizer_image_token("<image>x", tok) == [1, -200] + tok._ids("x")
+    assert P.tokenizer_image_token("plain", tok) == [1] + tok._ids("plain")
+
+    class NoBos(FakeTok):
+        def __call__(self, s):
+            return SimpleNamespace(input_ids=self._ids(s))
+    assert P.tokenizer_image_token("a<image>b", NoBos()) == NoBos()._ids("a") + [-200] + NoBos()._ids("b")
+
+
+def test_plan_batches_groups_sorts_and_covers():
+    args = [("bb", {"max_new_tokens": 8}), ("a", {"max_new_tokens": 8}), ("cccc", {"max_new_tokens": 16}),
+            ("ddd", {"max_new_tokens": 8}), ("eeeee", {"max_new_tokens": 8}), ("ab", {"max_new_tokens": 8})]
+    batches = P.plan_batches(args, len, 2)
+    assert sorted(i for b in batches for i in b) == list(range(6))
+    for b in batches:                                   # one generation-kwargs group per batch
+        assert len({str(args[i][1]) for i in b}) == 1 and len(b) <= 2
+    g8 = [i for b in batches for i in b if args[i][1]["max_new_tokens"] == 8]
+    assert g8 == [4, 3, 5, 0, 1]                        # longest first, ties by context string ("ab" < "bb")
+
+
+def test_gen_defaults():
+    g = P.gen_defaults({"until": ["\n"], "image_aspect_ratio": "pad"})
+    assert g == {"max_new_tokens": 1024, "temperature": 0, "top_p": None, "num_beams": 1}     # auroracap.py:468-476
+    assert P.gen_defaults({"max_new_tokens": 64})["max_new_tokens"] == 64
+    with pytest.raises(ValueError):
+        P.gen_defaults({"until": 3})
+    with pytest.raises(NotImplementedError):
+        P.gen_defaults({"temperature": 0.7})
+    with pytest.raises(NotImplementedError):
+        P.gen_defaults({"num_beams": 4})
+
+
+def test_generate_until_routes_and_restores_order():
+    m = make(batch_size=3)
+    docs = {i: np.zeros((2 + i % 3, 8, 8, 3), np.uint8) for i in range(7)}
+    m.task_dict = {"vdc": {"test": docs}}
+    ctxs = ["x" * (1 + (i * 5) % 7) for i in range(7)]
+    reqs = [SimpleNamespace(args=(ctxs[i], {"max_new_tokens": 32} if i % 2 else {}, lambda d: [d], i, "vdc", "test")) for i in range(7)]
+    out = m.generate_until(reqs)
+    assert len(out) == 7 and m.model.visual_encoder.ratio == 0.4
+    tok = FakeTok()
+    for i, text in enumerate(out):                     # each result belongs to ITS request, whatever the batch order was
+        f = 2 + i % 3
+        want_ids = P.tokenizer_image_token(P.conv_prompt(P.question_with_image_tokens(ctxs[i], f)), tok)
+        assert text == f"{f} {len(want_ids)} {f}"
+    assert sorted(m.model.calls) == sorted([(3, 1024), (1, 1024), (3, 32)])
+
+
+def test_plugin_loader_contract():
+    """lmms_eval/models/__init__.py:62-70: import <plugin>.models, read AVAILABLE_MODELS, import each class."""
+    m = importlib.import_module("aurora_amd.lmms_plugin.models")
+    for name, cls in m.AVAILABLE_MODELS.items():
+        mod = importlib.import_module(f"aurora_amd.lmms_plugin.models.{name}")
+        assert hasattr(mod, cls)
