@@ -563,27 +563,33 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     return AUR_OK;
 }
 
-extern "C" int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
-                              int32_t* n_kept_out, void* stream) {
+extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t height, int32_t width,
+                                 const void* pos_emb, int32_t r, void* out_tokens, int32_t* n_kept_out, void* stream) {
     if (!ctx->finalized || ctx->vl.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_vit_encode: vision weights not finalized");
     const aur_config& g = ctx->cfg;
     if (frames < 1 || frames > g.max_frames) return aur_fail(ctx, AUR_ERR_ARG, "frames %d outside [1, %d]", frames, g.max_frames);
     if (r < 0) return aur_fail(ctx, AUR_ERR_ARG, "r must be >= 0");
+    const int gh = height / g.vit_patch, gw = width / g.vit_patch, npatch = gh * gw, t0 = npatch + 1;
+    if (gh < 1 || gw < 1 || t0 > ctx->v_t0)
+        return aur_fail(ctx, AUR_ERR_ARG, "input %dx%d gives %d tokens per frame; this ctx holds up to %d (vit_image %d)", height, width,
+                        t0, ctx->v_t0, g.vit_image);
+    const bool native = gh == gw && npatch == ctx->v_npatch;
+    if (!pos_emb && !native) return aur_fail(ctx, AUR_ERR_ARG, "a %dx%d patch grid needs an interpolated position table (pos_emb)", gh, gw);
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "vit", s);
     const int D = g.vit_hidden;
-    CK(launch_im2col((const half_t*)pixels, frames, g.vit_channels, g.vit_image, g.vit_patch, ctx->v_kpad, ctx->w_col, s));
+    CK(launch_im2col((const half_t*)pixels, frames, g.vit_channels, height, width, g.vit_patch, ctx->v_kpad, ctx->w_col, s));
     GemmArgs pe{};
-    pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * ctx->v_npatch;
+    pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * npatch;
     pe.Npad = ctx->v_dpad; pe.K = ctx->v_kpad; pe.C = ctx->w_patch; pe.ldc = D; pe.n_real = D; pe.act = ACT_NONE;
     CK(launch_gemm(pe, EPI_ROW, s));
-    CK(launch_vit_assemble(ctx->w_patch, ctx->v_cls, ctx->v_pos, ctx->v_preln_w, ctx->v_preln_b, g.vit_ln_eps, frames,
-                           ctx->v_npatch, D, ctx->v_t0pad, ctx->w_xa, s));
+    CK(launch_vit_assemble(ctx->w_patch, ctx->v_cls, pos_emb ? (const half_t*)pos_emb : ctx->v_pos, ctx->v_preln_w, ctx->v_preln_b,
+                           g.vit_ln_eps, frames, npatch, D, rup(t0, 32), ctx->w_xa, s));
     half_t* x = ctx->w_xa;
     half_t* x_alt = ctx->w_xb;
     const float* size = nullptr;          // aurora.py:811: size = None at layer 0
     float* size_alt = ctx->w_sza;
-    int t = ctx->v_t0;
+    int t = t0;
     for (int l = 0; l < g.vit_layers - 1; ++l) {
         half_t* xr;
         const float* sr;
@@ -602,6 +608,11 @@ extern "C" int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, 
     if (n_kept_out) *n_kept_out = t - 1;
     stage_end(ctx, "vit", s);
     return AUR_OK;
+}
+
+extern "C" int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
+                              int32_t* n_kept_out, void* stream) {
+    return aur_vit_encode_hw(ctx, pixels, frames, ctx->cfg.vit_image, ctx->cfg.vit_image, nullptr, r, out_tokens, n_kept_out, stream);
 }
 
 extern "C" int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size, int32_t frames, int32_t t,

@@ -89,7 +89,7 @@ hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s);
 hipError_t launch_tome_metric(const KvLayout& kv, int frames, int t, int hd, float* metric, hipStream_t s);
 
 // ---- vit.hip
-hipError_t launch_im2col(const half_t* pixels, int frames, int chans, int img, int patch, int kpad, half_t* out,
+hipError_t launch_im2col(const half_t* pixels, int frames, int chans, int height, int width, int patch, int kpad, half_t* out,
                          hipStream_t s);
 hipError_t launch_vit_assemble(const half_t* patches, const half_t* cls, const half_t* pos, const float* ln_w,
                                const float* ln_b, float eps, int frames, int npatch, int d, int t_pad, half_t* x,

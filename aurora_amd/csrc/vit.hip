@@ -8,31 +8,32 @@
 
 // pixels [frames][chans][img][img] fp16 -> patches-as-rows [frames*gh*gw][kpad]; col = ch*P*P + ky*P + kx
 // (the flatten order of the conv weight [D, chans, P, P]); cols >= chans*P*P are zero (K padding).
-__global__ void im2col_kernel(const half_t* __restrict__ px, int frames, int chans, int img, int patch, int kpad,
+// height x width need not be the native square: the patch grid is (height / patch) x (width / patch), row-major,
+// pixels past the last whole patch are ignored (stride-`patch` convolution without padding).
+__global__ void im2col_kernel(const half_t* __restrict__ px, int frames, int chans, int height, int width, int patch, int kpad,
                               half_t* __restrict__ out) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int gw = img / patch;
-    const int64_t total = (int64_t)frames * gw * gw * kpad;
+    const int gw = width / patch, gh = height / patch;
+    const int64_t total = (int64_t)frames * gh * gw * kpad;
     if (id >= total) return;
     const int col = id % kpad;
     const int64_t row = id / kpad;
-    const int pxi = row % gw, pyi = (row / gw) % gw;
-    const int f = row / ((int64_t)gw * gw);
+    const int pxi = row % gw, pyi = (row / gw) % gh;
+    const int f = row / ((int64_t)gw * gh);
     half_t v = (half_t)0.f;
     if (col < chans * patch * patch) {
         const int ch = col / (patch * patch), rem = col % (patch * patch);
         const int ky = rem / patch, kx = rem % patch;
-        v = px[(((int64_t)f * chans + ch) * img + pyi * patch + ky) * img + pxi * patch + kx];
+        v = px[(((int64_t)f * chans + ch) * height + pyi * patch + ky) * width + pxi * patch + kx];
     }
     out[id] = v;
 }
 
-hipError_t launch_im2col(const half_t* pixels, int frames, int chans, int img, int patch, int kpad, half_t* out,
+hipError_t launch_im2col(const half_t* pixels, int frames, int chans, int height, int width, int patch, int kpad, half_t* out,
                          hipStream_t s) {
-    const int gw = img / patch;
-    const int64_t total = (int64_t)frames * gw * gw * kpad;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pixels, frames, chans, img,
-                       patch, kpad, out);
+    const int64_t total = (int64_t)frames * (height / patch) * (width / patch) * kpad;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pixels, frames, chans, height,
+                       width, patch, kpad, out);
     return hipGetLastError();
 }
 

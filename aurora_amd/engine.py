@@ -179,7 +179,9 @@ class AuroraCapEngine:
         rm[2 * qcols: 2 * qcols + D] = 2 * D + np.arange(D)
         self._set("vit.patch.w", self.pack(w["patch_embedding.weight"].reshape(D, -1), dpad, kpad))
         self._set("vit.cls", self._h(w["class_embedding"].reshape(-1)))
-        self._set("vit.pos", self._h(w["position_embedding.weight"]))
+        self._pos_native = self._h(w["position_embedding.weight"])       # kept for interpolated_pos()
+        self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        self._set("vit.pos", self._pos_native)
         self._set("vit.preln.w", self._f(w["pre_layrnorm.weight"]))
         self._set("vit.preln.b", self._f(w["pre_layrnorm.bias"]))
         nl = v["num_hidden_layers"] - 1          # hidden_states[-2]: the last layer is never needed
@@ -259,37 +261,64 @@ class AuroraCapEngine:
     def vit_encode(self, pixels: torch.Tensor, r: int) -> torch.Tensor:
         """pixels [F, C, H, W] -> hidden_states[-2][:, 1:]  as fp16 [F, n_kept, D]."""
         v = self.v
-        if pixels.dim() != 4 or pixels.shape[-1] != v["image_size"] or pixels.shape[-2] != v["image_size"]:
-            raise ValueError(f"pixel_values must be [frames, C, {v['image_size']}, {v['image_size']}], got {tuple(pixels.shape)}")
+        if pixels.dim() != 4 or pixels.shape[1] != v.get("num_channels", 3):
+            raise ValueError(f"pixel_values must be [frames, {v.get('num_channels', 3)}, H, W], got {tuple(pixels.shape)}")
         px = self._h(pixels)
-        F = px.shape[0]
-        t0 = (v["image_size"] // v["patch_size"]) ** 2 + 1
+        F, H, W = px.shape[0], px.shape[-2], px.shape[-1]
+        t0 = (H // v["patch_size"]) * (W // v["patch_size"]) + 1
+        if t0 < 2 or t0 > (v["image_size"] // v["patch_size"]) ** 2 + 1:
+            raise ValueError(f"a {H}x{W} input has {t0} tokens per frame; this engine holds up to "
+                             f"{(v['image_size'] // v['patch_size']) ** 2 + 1} (image_size {v['image_size']})")
         n_kept = tokens_at_layer(t0, r, v["num_hidden_layers"] - 1) - 1
         out = torch.empty(F, n_kept, v["hidden_size"], dtype=torch.float16, device=self.dev)
         nk = C.c_int32(0)
-        check(self.ctx, self.L.aur_vit_encode(self.ctx, px.data_ptr(), F, r, out.data_ptr(), C.byref(nk), self._stream()),
-              "aur_vit_encode")
+        pos = self.interpolated_pos(H, W)
+        check(self.ctx, self.L.aur_vit_encode_hw(self.ctx, px.data_ptr(), F, H, W, pos.data_ptr() if pos is not None else None, r,
+                                                 out.data_ptr(), C.byref(nk), self._stream()), "aur_vit_encode")
         assert nk.value == n_kept
         return out
 
-    def splice_plan(self, input_ids: Sequence[int], frames: int, n_kept: int):
+    def interpolated_pos(self, height: int, width: int) -> Optional[torch.Tensor]:
+        """Position table for a non-native input size (aurora.py:909-951): the n x n patch rows of the checkpoint's table
+        resampled bicubically to (height // patch, width // patch) with the reference's scale factors (g + 0.1) / n; None
+        for the native grid.  One-off weight preparation per input size (cached), done with torch on the device."""
+        v = self.v
+        gh, gw = height // v["patch_size"], width // v["patch_size"]
+        n = v["image_size"] // v["patch_size"]
+        if gh == n and gw == n:
+            return None
+        key = (gh, gw)
+        if key not in self._pos_cache:
+            pos = self._pos_native.float()
+            grid = pos[1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
+            out = torch.nn.functional.interpolate(grid, scale_factor=((gh + 0.1) / math.sqrt(n * n), (gw + 0.1) / math.sqrt(n * n)),
+                                                  mode="bicubic")
+            assert out.shape[-2] == gh and out.shape[-1] == gw
+            tab = torch.cat([pos[:1], out.permute(0, 2, 3, 1).reshape(gh * gw, -1)], dim=0)
+            self._pos_cache[key] = tab.to(torch.float16).contiguous()
+        return self._pos_cache[key]
+
+    def splice_plan(self, input_ids: Sequence[int], frames: int, n_kept, strict: bool = False):
         """Destination-row maps of the prefix splice for one prompt (model/utils.py:198-240 semantics: marker k takes
         frame k; markers beyond the number of frames are dropped), uploaded once.  Re-usable across calls: building it
         involves blocking host->device copies, which must stay out of a multi-stream pipeline's steady state."""
+        counts = [int(n_kept)] * frames if np.isscalar(n_kept) else [int(c) for c in n_kept]   # per-frame rows (slow-fast: ragged)
         vis_rows, text_ids, text_rows = [], [], []
         row, k = 0, 0
         for tid in input_ids:
             if tid == IMAGE_TOKEN_INDEX:
                 if k < frames:
-                    vis_rows.append(np.arange(row, row + n_kept))
-                    row += n_kept
+                    vis_rows.append(np.arange(row, row + counts[k]))
+                    row += counts[k]
+                elif strict:
+                    raise IndexError(f"image marker {k} has no frame ({frames} frames)")      # model/utils.py:361
                 k += 1
             else:
                 text_ids.append(int(tid))
                 text_rows.append(row)
                 row += 1
         vr = np.concatenate(vis_rows) if vis_rows else np.zeros(0, np.int64)
-        return dict(seq_len=row, used=len(vis_rows), n_kept=n_kept, ntext=len(text_ids),
+        return dict(seq_len=row, used=len(vis_rows), n_kept=n_kept, nvis=int(sum(counts[:len(vis_rows)])), ntext=len(text_ids),
                     vis_rows=torch.from_numpy(vr.astype(np.int32)).to(self.dev),
                     text_ids=torch.tensor(text_ids, dtype=torch.int32, device=self.dev),
                     text_rows=torch.tensor(text_rows, dtype=torch.int32, device=self.dev))
@@ -298,11 +327,16 @@ class AuroraCapEngine:
                        plan: Optional[dict] = None):
         """vis [frames, n_kept, Dv] + ids (with -200 markers) -> (embeds [L_pad, d] fp16, seq_len)."""
         d = self.l["hidden_size"]
-        if plan is None:
-            plan = self.splice_plan(input_ids, vis.shape[0], vis.shape[1])
-        assert plan["n_kept"] == vis.shape[1] and plan["used"] <= vis.shape[0]
-        seq_len, used = plan["seq_len"], plan["used"]
-        vflat = self._h(vis[:used]).reshape(used * plan["n_kept"], -1)
+        if vis.dim() == 2:                    # flat rows in marker order (frames with different token counts: slow-fast)
+            assert plan is not None and plan["nvis"] <= vis.shape[0]
+            seq_len = plan["seq_len"]
+            vflat = self._h(vis[:plan["nvis"]])
+        else:
+            if plan is None:
+                plan = self.splice_plan(input_ids, vis.shape[0], vis.shape[1])
+            assert plan["n_kept"] == vis.shape[1] and plan["used"] <= vis.shape[0]
+            seq_len, used = plan["seq_len"], plan["used"]
+            vflat = self._h(vis[:used]).reshape(used * plan["n_kept"], -1)
         embeds = out if out is not None else torch.empty(_rup(seq_len, 32), d, dtype=torch.float16, device=self.dev)
         assert embeds.shape[0] >= _rup(seq_len, 32) and embeds.is_contiguous()
         check(self.ctx, self.L.aur_project_splice(self.ctx, vflat.data_ptr(), vflat.shape[0], plan["vis_rows"].data_ptr(),

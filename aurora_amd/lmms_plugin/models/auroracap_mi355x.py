@@ -8,8 +8,8 @@ Differences, all on purpose:
   * the whole chunk of `batch_size` requests is captioned in ONE pass of the HIP engine
     (AuroraModel.caption_batch: batched ViT / prefill groups / 32-wide decode) instead of one clip at a time;
   * resize / crop / normalise run on the GPU (aurora_amd.preprocess, bit-identical to the CLIPImageProcessor call);
-  * sampling (temperature > 0), beams, slowfast and loglikelihood (broken in the reference: :240-290 reference
-    undefined names) raise NotImplementedError instead of failing later.
+  * sampling (temperature > 0), beams and loglikelihood (broken in the reference: :240-290 reference undefined
+    names) raise NotImplementedError instead of failing later; slowfast=True runs one clip at a time.
 
 llava (conversation templates, tokenizer_image_token) is a third-party package that is absent from the reference
 tree; its two published helpers are restated below.  With lmms_eval importable the class extends `lmms` and
@@ -117,8 +117,7 @@ class AuroraCapMI355X(_Base):
                  _preprocessor=None, **kwargs) -> None:
         super().__init__()
         assert kwargs == {}, f"Unexpected kwargs: {kwargs}"                 # auroracap.py:67
-        if slowfast:
-            raise NotImplementedError("slowfast=True is not implemented on the MI355X path")
+        self.slowfast = bool(slowfast)                                       # first frame unmerged (aurora.py:223-246)
         self._rank = int(os.environ.get("RANK", 0))                           # one process per GPU (accelerate / torchrun)
         self._world_size = int(os.environ.get("WORLD_SIZE", 1))
         local = int(os.environ.get("LOCAL_RANK", 0))
@@ -143,8 +142,8 @@ class AuroraCapMI355X(_Base):
             n_kept_max = per_frame - 31 * max(int(per_frame * (1 - self.token_merge_ratio) / 32), 0)
             self._model = AuroraModel.from_pretrained(
                 pretrained, max_frames=self.max_frames_num + 1, max_batch=min(self.batch_size_per_gpu, 32),
-                max_ctx=256 + (self.max_frames_num + 1) * n_kept_max + max_new_tokens, max_new_tokens=max_new_tokens,
-                device=str(self._device))
+                max_ctx=256 + (self.max_frames_num + 1) * n_kept_max + (per_frame if self.slowfast else 0) + max_new_tokens,
+                max_new_tokens=max_new_tokens, slowfast=self.slowfast, device=str(self._device))
             self._tokenizer = AutoTokenizer.from_pretrained(pretrained, trust_remote_code=True, padding_side="right")
             self._pre = FramePreprocessor(image=self.resolution, device=self._device)
         self._config = getattr(self._model, "config", None)
@@ -247,7 +246,15 @@ class AuroraCapMI355X(_Base):
                 prompt = conv_prompt(question_with_image_tokens(context, n_img), self.conv_template)
                 clips.append((pixel_values, tokenizer_image_token(prompt, self._tokenizer, IMAGE_TOKEN_INDEX)))
             self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)
-            ids = self._model.caption_batch(clips, max_new_tokens=gen["max_new_tokens"])
+            if self.slowfast:                   # ragged per-frame token counts: one clip at a time through the three calls
+                ids = []
+                for px, tok_ids in clips:
+                    self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)     # the slow-fast forward leaves it at 1.0
+                    out = self._model({"pixel_values": px.unsqueeze(0), "input_ids": torch.tensor([tok_ids])}, mode="inference")
+                    ids.append(self._model.llm.generate(**out, do_sample=False, num_beams=1,
+                                                        max_new_tokens=gen["max_new_tokens"])[0].tolist())
+            else:
+                ids = self._model.caption_batch(clips, max_new_tokens=gen["max_new_tokens"])
             texts = self._tokenizer.batch_decode(ids, skip_special_tokens=True)
             for i, text in zip(batch, texts):
                 res[i] = text

@@ -82,19 +82,20 @@ class _LLM:
 
 
 class AuroraModel:
-    def __init__(self, engine: AuroraCapEngine, eos_token_id: Optional[int] = 2):
+    def __init__(self, engine: AuroraCapEngine, eos_token_id: Optional[int] = 2, slowfast: bool = False):
         self.engine = engine
+        self.slowfast = slowfast                                                  # aurora.py:81 (AuroraModel(slowfast=...))
         self.visual_encoder = AuroraEncoder(engine)
         self.llm = _LLM(engine, eos_token_id)
 
     @classmethod
     def from_pretrained(cls, path: str, *, max_frames: int = 16, max_ctx: int = 8192, max_new_tokens: int = 2048,
-                        max_batch: int = 1, **kw):
+                        max_batch: int = 1, slowfast: bool = False, **kw):
         from .checkpoint import load_auroracap
         cfg, weights = load_auroracap(path)
         eng = AuroraCapEngine(cfg, weights, max_frames=max_frames, max_batch=max_batch, max_ctx=max_ctx,
                               max_new_tokens=max_new_tokens, **kw)
-        return cls(eng, cfg["llm"].get("eos_token_id", 2))
+        return cls(eng, cfg["llm"].get("eos_token_id", 2), slowfast=slowfast)
 
     def caption_batch(self, clips, max_new_tokens: int = 2048, eos_token_id="default"):
         """Several clips through the three calls at once (what a harness gets by looping inference.py:87-96 over its
@@ -125,7 +126,16 @@ class AuroraModel:
             raise ValueError(f"pixel_values must be [1, f, c, h, w] or [1, c, h, w], got {tuple(data['pixel_values'].shape)}")
         ids = data["input_ids"]
         ids = ids[0].tolist() if torch.is_tensor(ids) else list(ids[0])
-        vis = self.visual_encoder(px[0])                                          # aurora.py:249-253
-        embeds, L = self.engine.project_splice(vis, ids)                         # aurora.py:254-258
+        if self.slowfast and px.shape[1] != 1:                                    # aurora.py:223-246
+            low = self.visual_encoder(px[0, 1:])                                  # frames 1.. at the current ratio
+            self.visual_encoder.visual_token_merge_ratio = 1.0                    # :231 - the reference leaves it at 1.0 too
+            high = self.visual_encoder(px[0, :1])                                 # frame 0 unmerged
+            flat = torch.cat([high.reshape(-1, high.shape[-1]), low.reshape(-1, low.shape[-1])], 0)
+            counts = [high.shape[1]] + [low.shape[1]] * low.shape[0]
+            plan = self.engine.splice_plan(ids, px.shape[1], counts, strict=True)  # utils.py:297-431: marker i <- frame i
+            embeds, L = self.engine.project_splice(flat, plan=plan)
+        else:
+            vis = self.visual_encoder(px[0])                                      # aurora.py:249-253
+            embeds, L = self.engine.project_splice(vis, ids)                     # aurora.py:254-258
         return {"input_ids": None, "position_ids": None, "attention_mask": None, "past_key_values": None,
                 "inputs_embeds": embeds[:L].unsqueeze(0), "labels": None}         # utils.py:288-295

@@ -91,6 +91,13 @@ int32_t aur_tokens_at_layer(int32_t t0, int32_t r, int32_t layer);
  * out_tokens: fp16 [frames * n_kept, vit_hidden].  *n_kept_out (host) = kept tokens per frame. */
 int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
                    int32_t* n_kept_out, void* stream);
+/* Same for inputs that are not vit_image x vit_image (AuroraEncoder.interpolate_pos_encoding,
+ * aurora.py:909-951): pixels fp16 [frames, channels, height, width]; the patch grid is (height / patch) x (width / patch)
+ * and must fit the ctx ((h/p)*(w/p) + 1 <= (vit_image/patch)^2 + 1).  pos_emb: fp16 [1 + (h/p)*(w/p), vit_hidden], the
+ * position table the caller interpolated for this grid (bicubic, the reference's scale factors); NULL is allowed only
+ * for the native grid.  r is computed by the caller from height and width (aur_tome_r). */
+int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t height, int32_t width,
+                      const void* pos_emb, int32_t r, void* out_tokens, int32_t* n_kept_out, void* stream);
 
 /* projector + prefix splice: replaces self.projector(...) (aurora.py:254-256) and
  * prepare_inputs_labels_for_multimodal (model/utils.py:138-295) for one sequence.

@@ -137,14 +137,31 @@ def quick_gelu(x):
 ACT = {"quick_gelu": quick_gelu, "gelu": lambda x: F.gelu(x)}
 
 
+def interpolate_pos_encoding(pos: torch.Tensor, height: int, width: int, patch: int) -> torch.Tensor:
+    """aurora.py:909-951: position embedding [1 + N, D] for an input of height x width pixels.  Unchanged when the
+    patch grid is the native square one (:919-924); otherwise the N = n x n patch rows are resampled bicubically to
+    (height // patch, width // patch) with scale factors (g + 0.1) / n (:933-940), the class row is kept."""
+    w0, h0 = height // patch, width // patch                              # the reference's names (:915-916)
+    n_tok = pos.shape[0] - 1
+    if w0 * h0 == n_tok and w0 == h0:
+        return pos
+    n = int(math.sqrt(n_tok))
+    grid = pos[1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
+    out = F.interpolate(grid, scale_factor=((w0 + 0.1) / math.sqrt(n_tok), (h0 + 0.1) / math.sqrt(n_tok)), mode="bicubic")
+    assert out.shape[-2] == w0 and out.shape[-1] == h0                   # :941
+    return torch.cat([pos[:1], out.permute(0, 2, 3, 1).reshape(w0 * h0, -1)], dim=0)
+
+
 def vit_embed(pixels: torch.Tensor, w: Dict[str, torch.Tensor], patch: int, eps: float) -> torch.Tensor:
     """CLIPVisionEmbeddings + pre_layrnorm: conv(stride=patch, no bias) -> flatten row-major
-    -> prepend class_embedding -> + position_embedding -> LayerNorm (SURVEY 8a', a2)."""
+    -> prepend class_embedding -> + position_embedding -> LayerNorm (SURVEY 8a', a2).  The position table is the
+    one AuroraEncoder.forward installs for this input size first (aurora.py:892)."""
     f = pixels.shape[0]
     p = F.conv2d(pixels, w["patch_embedding.weight"], stride=patch)      # [f, D, gh, gw]
     p = p.flatten(2).transpose(1, 2)                                      # [f, gh*gw, D]
     cls = w["class_embedding"].expand(f, 1, -1)
-    x = torch.cat([cls, p], dim=1) + w["position_embedding.weight"][None, : p.shape[1] + 1]
+    pos = interpolate_pos_encoding(w["position_embedding.weight"], pixels.shape[-2], pixels.shape[-1], patch)
+    x = torch.cat([cls, p], dim=1) + pos[None, : p.shape[1] + 1]
     d = x.shape[-1]
     return F.layer_norm(x, (d,), w["pre_layrnorm.weight"], w["pre_layrnorm.bias"], eps)
 
@@ -240,6 +257,29 @@ def splice(input_ids: torch.Tensor, embed_table: torch.Tensor, visual: torch.Ten
         else:
             out.append(embed_table[tid][None])
     return torch.cat(out, dim=0)
+
+
+def splice_slowfast(input_ids: torch.Tensor, embed_table: torch.Tensor, visual: List[torch.Tensor]) -> torch.Tensor:
+    """prepare_inputs_labels_for_multimodal_slowfast (model/utils.py:297-431) for batch 1: marker i takes
+    visual[i] ([n_i, d], token counts differ per frame); unlike the plain splice a marker without a frame is an
+    error (:361 indexes the list directly)."""
+    out = []
+    k = 0
+    for tid in input_ids.tolist():
+        if tid == IMAGE_TOKEN_INDEX:
+            out.append(visual[k].reshape(-1, visual[k].shape[-1]))
+            k += 1
+        else:
+            out.append(embed_table[tid][None])
+    return torch.cat(out, dim=0)
+
+
+def visual_features_slowfast(pixels, vw, pw, cfg, token_kept_ratio, q: Q = None) -> List[torch.Tensor]:
+    """aurora.py:223-246: frames 1.. at the current ratio, then frame 0 at ratio 1.0 (unmerged); each projected.
+    Returns the list [frame0 [n0, d], frame1 [n, d], ...] that the slow-fast splice consumes."""
+    low = vit_features(pixels[1:], vw, cfg, token_kept_ratio, q)
+    high = vit_features(pixels[:1], vw, cfg, 1.0, q)
+    return [projector(high[0], pw, q)] + [projector(x, pw, q) for x in low]
 
 
 def build_prompt(prompt: str, num_images: int) -> str:

@@ -55,8 +55,7 @@ def test_reference_defaults_and_surface():
     assert m.batch_size == 4 and m.rank == 0 and m.world_size == 1 and m.eot_token_id == 2
     with pytest.raises(AssertionError):
         make(bogus=1)
-    with pytest.raises(NotImplementedError):
-        make(slowfast=True)
+    assert make(slowfast=True).slowfast is True and m.slowfast is False
     with pytest.raises(NotImplementedError):
         m.loglikelihood([])
 
