@@ -4,7 +4,7 @@
 // Reference: third-party transformers LlamaForCausalLM.generate greedy loop as called at
 // inference.py:89-96 (one position per step with a KV cache, argmax, EOS / max_new_tokens stop).
 //
-// skinny GEMM   y[b, n] = sum_k x[b, k] W[n, k]   for b <= 32 rows:
+// skinny GEMM   y[b, n] = sum_k x[b, k] W[n, k]   for b <= 64 rows (1-4 MFMA column groups of 16):
 //   * Weights are the same FRAG tiles the prefill GEMM uses ([N/16][K/32][64][8]); a wave streams one
 //     1 KiB fragment per global_load_dwordx4 (non-temporal) straight into VGPRs - no LDS round trip for a
 //     once-read operand.
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    if (a.ssq_zero && blockIdx.x == 0 && tid < 32) a.ssq_zero[tid] = 0ull;     // reset the accumulator a LATER kernel fills
+    if (a.ssq_zero && blockIdx.x == 0 && tid < AUR_MAX_BATCH) a.ssq_zero[tid] = 0ull;     // reset the accumulator a LATER kernel fills
     const int K32 = a.K >> 5;
     const int tile0 = blockIdx.x * NT;
 
@@ -67,6 +67,48 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
     for (int nb = 0; nb < NB; ++nb) xp[nb] = a.xf + ((int64_t)nb * K32 + w) * AUR_FRAG_HALVES + lane * 8;
     constexpr int64_t STEP = (int64_t)NW * AUR_FRAG_HALVES;
     const int nfull = nit / U * U;
+    int i0 = 0;
+    if constexpr (NB > 2) {
+        // 3-4 column groups: x fragments (L2 hits) outnumber the weight fragments, so they get their own shallow
+        // pipeline (a ring of U register buffers, U-1 k32 tiles ahead) and the HBM stream keeps its full depth of U tiles.
+        h8 cw[U][NT], nw[U][NT], xr[U][NB];
+        if (nfull > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cw[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + u * STEP));
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) xr[u][nb] = *(const h8*)(xp[nb] + u * STEP);
+        }
+        for (; i0 < nfull; i0 += U) {
+            const bool more = (i0 + 2 * U <= nfull);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) nw[u][t] = __builtin_nontemporal_load((const h8*)(wp[t] + (i0 + U + u) * STEP));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u + U - 1 < U || more) {                  // tile i0 + u + U-1 lies in a full batch: buffer (u + U-1) % U
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) xr[(u + U - 1) % U][nb] = *(const h8*)(xp[nb] + (i0 + u + U - 1) * STEP);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(cw[u][t], xr[u][nb], acc[t][nb]);
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) cw[u][t] = nw[u][t];
+            }
+        }
+    } else {
     h8 cw[U][NT], cx[U][NB], nw[U][NT], nx[U][NB];
     if (nfull > 0) {
 #pragma unroll
@@ -77,7 +119,6 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
             for (int nb = 0; nb < NB; ++nb) cx[u][nb] = *(const h8*)(xp[nb] + u * STEP);
         }
     }
-    int i0 = 0;
     for (; i0 < nfull; i0 += U) {
         const bool more = (i0 + 2 * U <= nfull);            // wave-uniform: one branch per batch
         if (more) {
@@ -104,6 +145,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
                 for (int nb = 0; nb < NB; ++nb) cx[u][nb] = nx[u][nb];
             }
         }
+    }
     }
     for (; i0 < nit; ++i0) {                     // tail (< U tiles)
         h8 xf[NB];
@@ -247,8 +289,13 @@ static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    if (a.B < 1 || a.B > 32 || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
-    return a.B > 16 ? launch_skinny_nb<2>(a, s) : launch_skinny_nb<1>(a, s);
+    if (a.B < 1 || a.B > AUR_MAX_BATCH || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
+    switch ((a.B + 15) >> 4) {                              // MFMA column groups of 16 batch rows
+        case 1: return launch_skinny_nb<1>(a, s);
+        case 2: return launch_skinny_nb<2>(a, s);
+        case 3: return launch_skinny_nb<3>(a, s);
+        default: return launch_skinny_nb<4>(a, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------ x-fragment producers

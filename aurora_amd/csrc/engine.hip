@@ -218,8 +218,8 @@ static int64_t carve(aur_ctx* c, char* base) {
     for (int bk = 0; bk < 2; ++bk) {
         aur_ctx::Bank& K = c->banks[bk];
         K.d_x = k.take<half_t>(Bp * d);                    // residual stream    (x-fragment form)
-        K.s_ssq_mlp = k.take<unsigned long long>(32);      // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
-        K.s_ssq_attn = k.take<unsigned long long>(32);     // sum(x^2) per row after the attention residual
+        K.s_ssq_mlp = k.take<unsigned long long>(AUR_MAX_BATCH);      // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
+        K.s_ssq_attn = k.take<unsigned long long>(AUR_MAX_BATCH);     // sum(x^2) per row after the attention residual
         K.d_logits = k.take<float>(B * g.llm_vocab);
         K.s_pos = k.take<int32_t>(B);
         K.s_ids = k.take<int32_t>(B * g.max_new_tokens);
@@ -229,7 +229,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_q = k.take<half_t>(B * d);
     c->d_attn = k.take<half_t>(Bp * d);                    // attention output  (x-fragment form)
     c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
-    c->d_scr = k.take<half_t>(32 * 16384);                 // scratch x-fragments for aur_linear_skinny
+    c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * B * c->l_max_pages);
@@ -250,7 +250,7 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
         return aur_fail(nullptr, AUR_ERR_ARG, "vit dims: hidden/mlp must be multiples of 64, head_dim a multiple of 16");
     if (g.llm_hidden % 128 || g.llm_mlp % 128 || g.llm_hidden % g.llm_heads || (g.llm_hidden / g.llm_heads) % 32)
         return aur_fail(nullptr, AUR_ERR_ARG, "llm dims: hidden/mlp must be multiples of 128, head_dim a multiple of 32");
-    if (g.max_batch < 1 || g.max_batch > 32) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, 32]");
+    if (g.max_batch < 1 || g.max_batch > AUR_MAX_BATCH) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, %d]", AUR_MAX_BATCH);
     if (g.page_tokens < 64 || g.page_tokens % 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be a multiple of 64");
     if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
     {
@@ -689,11 +689,11 @@ extern "C" int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, con
 }
 extern "C" int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
                                  int32_t n, float* out, void* stream) {
-    if (m < 1 || m > 32 || (k & 127) || k > 16384 || (npad & 31) || n > npad || (n & 3))
-        return aur_fail(ctx, AUR_ERR_ARG, "aur_linear_skinny: need m <= 32, k %% 128 == 0, k <= 16384");
+    if (m < 1 || m > AUR_MAX_BATCH || (k & 127) || k > 16384 || (npad & 31) || n > npad || (n & 3))
+        return aur_fail(ctx, AUR_ERR_ARG, "aur_linear_skinny: need m <= %d, k %% 128 == 0, k <= 16384", AUR_MAX_BATCH);
     if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_linear_skinny: workspace not set");
     hipStream_t st = (hipStream_t)stream;
-    CK(hipMemsetAsync(ctx->d_scr, 0, (size_t)32 * 16384 * 2, st));
+    CK(hipMemsetAsync(ctx->d_scr, 0, (size_t)AUR_MAX_BATCH * 16384 * 2, st));
     CK(launch_xfrag_pack((const half_t*)a, k, m, k, ctx->d_scr, st));
     SkinnyArgs s{};
     s.xf = ctx->d_scr; s.W = (const half_t*)w_packed; s.B = m; s.b_lo = 0; s.b_hi = m; s.Npad = npad; s.K = k; s.n_real = n;
@@ -772,8 +772,8 @@ extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_toke
     CK(hipMemsetAsync(ctx->s_ids, 0, (size_t)g.max_batch * g.max_new_tokens * 4, s));
     const size_t bp = (size_t)rup(g.max_batch, 16);       // unused fragment lanes must hold finite values
     CK(hipMemsetAsync(ctx->d_x, 0, bp * g.llm_hidden * 2, s));          // bank-owned buffers only: the other bank may be decoding
-    CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, 32 * 8, s));
-    CK(hipMemsetAsync(ctx->s_ssq_attn, 0, 32 * 8, s));
+    CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, AUR_MAX_BATCH * 8, s));
+    CK(hipMemsetAsync(ctx->s_ssq_attn, 0, AUR_MAX_BATCH * 8, s));
     return AUR_OK;
 }
 

@@ -141,7 +141,7 @@ class AuroraCapMI355X(_Base):
             per_frame = (self.resolution // 14) ** 2                            # CLIP ViT-H/14, 32 layers (aurora.py:895)
             n_kept_max = per_frame - 31 * max(int(per_frame * (1 - self.token_merge_ratio) / 32), 0)
             self._model = AuroraModel.from_pretrained(
-                pretrained, max_frames=self.max_frames_num + 1, max_batch=min(self.batch_size_per_gpu, 32),
+                pretrained, max_frames=self.max_frames_num + 1, max_batch=min(self.batch_size_per_gpu, 64),
                 max_ctx=256 + (self.max_frames_num + 1) * n_kept_max + (per_frame if self.slowfast else 0) + max_new_tokens,
                 max_new_tokens=max_new_tokens, slowfast=self.slowfast, device=str(self._device))
             self._tokenizer = AutoTokenizer.from_pretrained(pretrained, trust_remote_code=True, padding_side="right")

@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--batch", type=int, default=32, help="clips per GPU per step (decode slots; <= 32)")
+    p.add_argument("--batch", type=int, default=64, help="clips per GPU per step (decode slots; <= 64)")
     p.add_argument("--num_frm", type=int, default=8)
     p.add_argument("--token_kept_ratio", type=float, default=0.3)
     p.add_argument("--max_new_tokens", type=int, default=256)

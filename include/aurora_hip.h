@@ -47,7 +47,7 @@ typedef struct aur_config {
     float llm_rms_eps, rope_theta, rope_factor;   /* linear RoPE scaling factor (vicuna-16k: 4.0) */
     /* capacity */
     int32_t max_frames;         /* frames per aur_vit_encode call */
-    int32_t max_batch;          /* decode slots (sequences resident in the KV pool), <= 32 */
+    int32_t max_batch;          /* decode slots (sequences resident in the KV pool), <= 64 */
     int32_t max_ctx;            /* tokens per sequence (prompt + generated) */
     int32_t max_new_tokens;     /* output buffer width per slot */
     int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
@@ -143,7 +143,7 @@ int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, const float*
  * (npad % 128 == 0, K % 64 == 0); bias fp32 [npad] or NULL; act 0 / AUR_ACT_*; resid fp16 [M, n] or NULL. */
 int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
                int32_t n, const float* bias, int32_t act, const void* resid, void* c, void* stream);
-/* Same contraction through the decode (m <= 32) weight-streaming kernel; out fp32 [m, n]. */
+/* Same contraction through the decode (m <= 64) weight-streaming kernel; out fp32 [m, n]. */
 int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
                       int32_t n, float* out, void* stream);
 int aur_layernorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d, const float* w, const float* b,

@@ -56,7 +56,8 @@ def test_linear_epilogues(eng):
 
 
 @pytest.mark.parametrize("b,n,k", [(1, 128, 128), (3, 256, 512), (8, 384, 4096), (16, 128, 1024), (8, 256, 11008), (5, 320, 640),
-                                   (17, 256, 512), (24, 128, 4096), (32, 384, 11008)])
+                                   (17, 256, 512), (24, 128, 4096), (32, 384, 11008), (33, 256, 1024), (48, 128, 4096),
+                                   (64, 384, 11008), (57, 320, 640)])
 def test_skinny_linear_matches_fp32(eng, b, n, k):
     g = torch.Generator().manual_seed(b * 13 + n)
     a = (torch.randn(b, k, generator=g) * 0.5).half()

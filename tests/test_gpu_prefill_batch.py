@@ -59,6 +59,30 @@ def test_two_banks_overlapped_streams_equal_sequential():
         eng.close()
 
 
+def test_batch_of_52_four_column_groups_equals_single():
+    """Up to 64 slots = four MFMA column groups in the decode GEMVs; ragged prompts, EOS stopping per slot."""
+    cfg = LLM_CFGS["hd64"]
+    gen = torch.Generator().manual_seed(33)
+    lens = [40 + (7 * i) % 90 for i in range(52)]
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
+    eng, w = make_engine(cfg, 13, max_batch=52, use_graph=True, max_ctx=256, max_new=10)
+    try:
+        together = eng.generate([padded(e) for e in embs], lens, 10, eos_id=None)
+        for b in (0, 15, 16, 31, 32, 33, 47, 48, 51):
+            alone = eng.generate([padded(embs[b])], [lens[b]], 10, eos_id=None)[0]
+            assert together[b] == alone, b
+        eos = together[40][4]
+        stopped = eng.generate([padded(e) for e in embs], lens, 10, eos_id=eos)
+        for b in range(52):
+            want = together[b][: together[b].index(eos) + 1] if eos in together[b] else together[b]
+            assert stopped[b] == want, b
+    finally:
+        eng.close()
+    from aurora_amd._lib import AuroraHipError
+    with pytest.raises(AuroraHipError):
+        make_engine(cfg, 13, max_batch=65)
+
+
 def test_batch_of_20_two_column_groups_equals_single():
     """More than 16 slots use two MFMA column groups in the decode GEMVs; every slot must still generate exactly
     what it generates alone (batch-invariant arithmetic), including ragged prompt lengths."""
