@@ -72,7 +72,10 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
     const int a_off1 = wr * G2_SLOT + r * 128 + (((1 * 4 + g) ^ sw) << 4);       // kk = 1
     const int w_off = (wc >> 1) * G2_SLOT + (wc & 1) * 8192 + lane * 16;
 
-    h8 af[8], wf[4];      // af[uu*2+kk]: 4 m-tiles of the current M half; wf[tt*2+kk]: 2 n-tiles of the current N half
+    // af[uu*2+kk]: 4 m-tiles of the current M half; wf0 / wf1 [tt*2+kk]: 2 n-tiles of N half 0 / 1.  N half 0 is used by the
+    // first and the last quadrant of a K-tile and stays in registers in between (LDS read bandwidth is the co-limiter:
+    // 24 KiB per wave per K-tile instead of 28)
+    h8 af[8], wf0[4], wf1[4];
     auto read_a = [&](const char* buf, int mh) {
 #pragma unroll
         for (int uu = 0; uu < 4; ++uu) {
@@ -80,14 +83,14 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
             af[uu * 2 + 1] = *(const h8*)(buf + a_off1 + (mh * 4 + uu) * 2048);
         }
     };
-    auto read_w = [&](const char* buf, int nh) {
+    auto read_w = [&](const char* buf, int nh, h8 (&wf)[4]) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             wf[tt * 2 + 0] = *(const h8*)(buf + w_off + (nh * 2 + tt) * 2048);
             wf[tt * 2 + 1] = *(const h8*)(buf + w_off + (nh * 2 + tt) * 2048 + 1024);
         }
     };
-#define G2_COMPUTE(NH, MH)                                                                                   \
+#define G2_COMPUTE(NH, MH, wf)                                                                                   \
     do {                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -127,25 +130,24 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
         const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;     // block-uniform
         // phase 0: quadrant (n half 0, m half 0)
         read_a(abuf, 0);
-        read_w(wbuf, 0);
+        read_w(wbuf, 0, wf0);
         if (n1) stage_a(1, t + 1);
         G2_BARRIER();
-        G2_COMPUTE(0, 0);
+        G2_COMPUTE(0, 0, wf0);
         G2_BARRIER();
         // phase 1: (n half 1, m half 0)
-        read_w(wbuf, 1);
+        read_w(wbuf, 1, wf1);
         if (n2) stage_w(0, t + 2, wb2);
         G2_BARRIER();
-        G2_COMPUTE(1, 0);
+        G2_COMPUTE(1, 0, wf1);
         G2_BARRIER();
         // phase 2: (n half 1, m half 1)
         read_a(abuf, 1);
         if (n2) stage_w(1, t + 2, wb2);
         G2_BARRIER();
-        G2_COMPUTE(1, 1);
+        G2_COMPUTE(1, 1, wf1);
         G2_BARRIER();
         // phase 3: (n half 0, m half 1); retire K-tile t+1's half-tiles, keep W0, W1, A0 of t+2 in flight
-        read_w(wbuf, 0);
         if (n2) {
             stage_a(0, t + 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -153,7 +155,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         G2_BARRIER();
-        G2_COMPUTE(0, 1);
+        G2_COMPUTE(0, 1, wf0);
         G2_BARRIER();
         wb = wb == 2 ? 0 : wb + 1;
     }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=320)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--nseq", type=int, default=1, help="sequences per prefill pass for the pre_* kernels (<= batch)")
     args = ap.parse_args()
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup
@@ -40,13 +41,14 @@ def main():
         emb = (torch.randn(_rup(L0, 32), d, generator=g, device="cuda") * 0.02).half()
         eng.prefill(b, emb, L0)
     torch.cuda.synchronize()
-    M = _rup(L0, 32)
+    eng.set_option("microbench_prefill_nseq", min(args.nseq, B))
+    M = _rup(L0, 32) * min(args.nseq, B)
     kv_bytes = B * (L0 + 1) * 2 * d * 2
     work = {   # kernel -> (unit, amount per launch)
         "dec_qkv": ("GB/s", 3 * d * d * 2), "dec_o": ("GB/s", d * d * 2), "dec_gateup": ("GB/s", 2 * mlp * d * 2),
         "dec_down": ("GB/s", mlp * d * 2), "dec_lm_head": ("GB/s", V * d * 2), "dec_attn": ("GB/s", kv_bytes),
         "pre_qkv": ("TF/s", 2 * M * 3 * d * d), "pre_o": ("TF/s", 2 * M * d * d), "pre_gateup": ("TF/s", 2 * M * 2 * mlp * d),
-        "pre_down": ("TF/s", 2 * M * mlp * d), "pre_attn": ("TF/s", 2 * L0 * L0 * d), "pre_norm": ("GB/s", 2 * M * d * 2),
+        "pre_down": ("TF/s", 2 * M * mlp * d), "pre_attn": ("TF/s", 2 * L0 * L0 * d * min(args.nseq, B)), "pre_norm": ("GB/s", 2 * M * d * 2),
     }
     res = {}
 
