@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
+    p.add_argument("--decode-chunk", type=int, default=0,
+                   help="synchronise every N decode steps (rocprofv3 --kernel-trace segfaults with > ~150 hipGraph launches queued)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
     return p.parse_args()
 
@@ -176,7 +178,12 @@ def main():
     def back(bank):
         """Decode of the batch in `bank`, result copy (synchronises the decode stream) and the cross-rank gather."""
         eng.select_bank(bank)
-        eng.decode(N - 1)
+        if args.decode_chunk > 0:                                  # profiling aid: bound the number of queued graph launches
+            for s0 in range(0, N - 1, args.decode_chunk):
+                eng.decode(min(args.decode_chunk, N - 1 - s0))
+                torch.cuda.current_stream().synchronize()
+        else:
+            eng.decode(N - 1)
         out = eng.outputs()
         if world > 1:
             parallel.gather_results(out, N, B, dev)                # RCCL all_gather over xGMI
