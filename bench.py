@@ -110,11 +110,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # AURORA_DIST_BACKEND=gloo is a TEST hook: it lets `torchrun --nproc-per-node 2 bench.py --gpus 2 --tiny` exercise the
+    # multi-rank control flow on a one-GPU box (ranks share the device, collectives carry CPU tensors).  Default: RCCL.
+    backend = os.environ.get("AURORA_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     from aurora_amd import parallel
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup, tokens_at_layer, tome_r
@@ -130,6 +138,7 @@ def main():
     B, F, N = args.batch, args.num_frm, args.max_new_tokens
     pipe = args.pipeline
     dev = f"cuda:{local}"
+    cdev = dev if backend == "nccl" else "cpu"                     # where collective payloads live
     weights = {"vit": S.vit_weights(v, device=dev), "projector": S.projector_weights(v["hidden_size"], l["hidden_size"], device=dev),
                "llm": S.llm_weights(l, device=dev)}
     t0tok = (v["image_size"] // v["patch_size"]) ** 2 + 1
@@ -175,8 +184,9 @@ def main():
                 evs.extend([e] * n)
         return ev0, evs
 
-    def back(bank):
-        """Decode of the batch in `bank`, result copy (synchronises the decode stream) and the cross-rank gather."""
+    def back(bank, gather=True):
+        """Decode of the batch in `bank`, result copy (synchronises the decode stream) and the cross-rank gather.
+        gather=False for rank-local passes (the instrumented step runs on rank 0 only: no collective may be in it)."""
         eng.select_bank(bank)
         if args.decode_chunk > 0:                                  # profiling aid: bound the number of queued graph launches
             for s0 in range(0, N - 1, args.decode_chunk):
@@ -185,8 +195,8 @@ def main():
         else:
             eng.decode(N - 1)
         out = eng.outputs()
-        if world > 1:
-            parallel.gather_results(out, N, B, dev)                # RCCL all_gather over xGMI
+        if world > 1 and gather:
+            parallel.gather_results(out, N, B, cdev)               # RCCL all_gather over xGMI
         return out
 
     def fence():
@@ -251,7 +261,7 @@ def main():
         eng.select_bank(0)
     assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -282,7 +292,7 @@ def main():
         eng.select_bank(0)
         eng.profile(True)
         front(0)
-        back(0)
+        back(0, gather=False)
         stages = {k: eng.profile_read(k)[0] for k in ("vit", "project", "prefill", "decode")}
         ams, an = eng.profile_read("decode_attn")
         kms, kn = eng.profile_read("decode_gemm_gateup")
@@ -349,6 +359,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()                                             # rank 0 arrives last (instrumented pass): leave together
         dist.destroy_process_group()
 
 

@@ -1,0 +1,53 @@
+"""GPU: bench.py in the driver's launch modes (tiny model dims: plumbing, not the metric).
+
+The two-rank case runs `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` exactly as the
+driver does, with AURORA_DIST_BACKEND=gloo so that both ranks can share the single GPU of the test box (collectives
+carry CPU tensors instead of going through RCCL).  It guards the multi-rank control flow: barriers, the per-step result
+gather, max-over-ranks timing, the rank-0-only instrumented pass (no collective may hide in it) and a clean exit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = ["--tiny", "--batch", "4", "--num_frm", "2", "--max_new_tokens", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + TINY, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipeline"]])
+def test_two_ranks_torchrun_gloo(extra):
+    env = dict(os.environ, AURORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + TINY + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["clips_per_gpu_per_step"] == 4                       # weak scaling: per-GPU work fixed
+    assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]     # whole-job aggregate
