@@ -270,15 +270,15 @@ extern "C" void aur_destroy(aur_ctx* ctx) {
     if (!ctx) return;
     ctx->banks[ctx->cur_bank].graph = ctx->graph;
     for (auto& K : ctx->banks)
-        if (K.graph) hipGraphExecDestroy(K.graph);
+        if (K.graph) (void)hipGraphExecDestroy(K.graph);
     for (auto& kv : ctx->timers) {
-        if (kv.second.e0) hipEventDestroy(kv.second.e0);
-        if (kv.second.e1) hipEventDestroy(kv.second.e1);
+        if (kv.second.e0) (void)hipEventDestroy(kv.second.e0);
+        if (kv.second.e1) (void)hipEventDestroy(kv.second.e1);
     }
     for (auto& kv : ctx->kev)
         for (auto& p : kv.ev) {
-            hipEventDestroy(p.first);
-            hipEventDestroy(p.second);
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
         }
     delete ctx;
 }
@@ -410,22 +410,22 @@ static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
     if (!t.e0) {
-        hipEventCreate(&t.e0);
-        hipEventCreate(&t.e1);
+        (void)hipEventCreate(&t.e0);
+        (void)hipEventCreate(&t.e1);
     }
     if (t.open) {      // fold the previous interval
-        hipEventSynchronize(t.e1);
+        (void)hipEventSynchronize(t.e1);
         float ms = 0;
-        hipEventElapsedTime(&ms, t.e0, t.e1);
+        (void)hipEventElapsedTime(&ms, t.e0, t.e1);
         t.ms += ms;
         t.open = false;
     }
-    hipEventRecord(t.e0, s);
+    (void)hipEventRecord(t.e0, s);
 }
 static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
-    hipEventRecord(t.e1, s);
+    (void)hipEventRecord(t.e1, s);
     t.open = true;
     t.launches++;
 }
@@ -445,7 +445,7 @@ extern "C" int aur_profile_enable(aur_ctx* ctx, int32_t on) {
 }
 static void kev_fold(aur_ctx::KernelEvents& k) {
     for (size_t i = 0; i < k.used; ++i) {
-        hipEventSynchronize(k.ev[i].second);
+        (void)hipEventSynchronize(k.ev[i].second);
         float ms = 0;
         if (hipEventElapsedTime(&ms, k.ev[i].first, k.ev[i].second) == hipSuccess) {
             k.ms += ms;
@@ -457,14 +457,14 @@ static void kev_fold(aur_ctx::KernelEvents& k) {
 static void kev_begin(aur_ctx::KernelEvents& k, hipStream_t s) {
     if (k.used == k.ev.size()) {
         hipEvent_t a, b;
-        hipEventCreate(&a);
-        hipEventCreate(&b);
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
         k.ev.push_back({a, b});
     }
-    hipEventRecord(k.ev[k.used].first, s);
+    (void)hipEventRecord(k.ev[k.used].first, s);
 }
 static void kev_end(aur_ctx::KernelEvents& k, hipStream_t s) {
-    hipEventRecord(k.ev[k.used].second, s);
+    (void)hipEventRecord(k.ev[k.used].second, s);
     k.used++;
     if (k.used >= 4096) kev_fold(k);
 }
@@ -484,9 +484,9 @@ extern "C" int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out,
     }
     StageTimer& t = it->second;
     if (t.open) {
-        hipEventSynchronize(t.e1);
+        (void)hipEventSynchronize(t.e1);
         float ms = 0;
-        hipEventElapsedTime(&ms, t.e0, t.e1);
+        (void)hipEventElapsedTime(&ms, t.e0, t.e1);
         t.ms += ms;
         t.open = false;
     }
@@ -904,9 +904,8 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
 
 static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
     const aur_config& g = ctx->cfg;
-    const int d = g.llm_hidden, B = ctx->batch;
+    const int B = ctx->batch;
     for (int l = 0; l < g.llm_layers; ++l) {
-        const LlmLayerW& w = ctx->ll[l];
         CK(launch_skinny(mk_dec_qkv(ctx, l), s));
         {
             const DecAttnArgs at = mk_dec_attn(ctx, l);
@@ -934,7 +933,7 @@ extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
     if (use_graph) {
         if (!ctx->graph || ctx->graph_batch != ctx->batch) {
             if (ctx->graph) {
-                hipGraphExecDestroy(ctx->graph);
+                (void)hipGraphExecDestroy(ctx->graph);
                 ctx->graph = nullptr;
             }
             hipGraph_t gr;
@@ -944,7 +943,7 @@ extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
             if (rc) return rc;
             if (e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             CK(hipGraphInstantiate(&ctx->graph, gr, nullptr, nullptr, 0));
-            hipGraphDestroy(gr);
+            (void)hipGraphDestroy(gr);
             ctx->graph_batch = ctx->batch;
         }
         for (int i = 0; i < steps; ++i) CK(hipGraphLaunch(ctx->graph, s));
@@ -995,7 +994,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
     } else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
     if (ctx->graph) {             // kernel arguments are frozen in the captured graph
-        hipGraphExecDestroy(ctx->graph);
+        (void)hipGraphExecDestroy(ctx->graph);
         ctx->graph = nullptr;
     }
     return AUR_OK;
@@ -1042,8 +1041,8 @@ extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, d
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *us_out = 1e3 * ms / iters;
     return AUR_OK;
 }
