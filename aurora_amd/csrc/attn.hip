@@ -46,8 +46,46 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         nkb = nkb < lim ? nkb : lim;
     }
 
+    // 64-token pages (the paged KV cache): key block kb IS page kb of the sequence, whose K fragments of this head are
+    // 4*KBLK contiguous KiB and whose V^T fragments are 2*VD16 contiguous KiB -> ONE page-table lookup per block (fetched a
+    // block ahead) and constant offsets, instead of an integer division + dependent table load per fragment.
+    const bool p64 = kv.page_tokens == 64 && kv.page_table != nullptr;
+    const int32_t* prow = p64 ? kv.page_table + (int64_t)(a.seq0 + seq) * kv.max_pages : nullptr;
+    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8, voff = vfrag_off(kv, head, 0, 0) + lane * 8;
+    int pid_next = p64 ? prow[0] : 0;
     auto stage = [&](int kb, int buf) {
         char* dst = smem + buf * (NF * 1024);
+        if (p64) {
+            const half_t* page = kv.base + (int64_t)pid_next * kv.page_halves;
+            if (kb + 1 < nkb) pid_next = prow[kb + 1];
+#pragma unroll
+            for (int i = 0; i < NF / 4; ++i) {
+                const int f = w + 4 * i;
+                glds16(f < 4 * KBLK ? page + koff + f * AUR_FRAG_HALVES : page + voff + (f - 4 * KBLK) * AUR_FRAG_HALVES, dst + f * 1024);
+            }
+            for (int f = w + 4 * (NF / 4); f < NF; f += 4)
+                glds16(f < 4 * KBLK ? page + koff + f * AUR_FRAG_HALVES : page + voff + (f - 4 * KBLK) * AUR_FRAG_HALVES, dst + f * 1024);
+            return;
+        }
+        if (kv.page_table == nullptr && kv.page_tokens >= a.rows_per_seq) {     // one "page" per sequence (ViT frames): no division
+            const half_t* page = kv.base + (int64_t)(a.seq0 + seq) * kv.page_halves;
+            const int t16pp = kv.page_tokens >> 4, t32pp = kv.page_tokens >> 5;
+            for (int f = w; f < NF; f += 4) {
+                const half_t* src;
+                if (f < 4 * KBLK) {
+                    int t16 = kb * 4 + f / KBLK;
+                    t16 = t16 < T16 ? t16 : T16 - 1;
+                    src = page + (((int64_t)head * t16pp + t16) * KBLK + f % KBLK) * AUR_FRAG_HALVES;
+                } else {
+                    const int fv = f - 4 * KBLK;
+                    int t32 = kb * 2 + (fv & 1);
+                    t32 = t32 < T32 ? t32 : T32 - 1;
+                    src = page + kv.v_off + (((int64_t)head * VD16 + (fv >> 1)) * t32pp + t32) * AUR_FRAG_HALVES;
+                }
+                glds16(src + lane * 8, dst + f * 1024);
+            }
+            return;
+        }
         for (int f = w; f < NF; f += 4) {
             const half_t* src;
             if (f < 4 * KBLK) {
@@ -97,14 +135,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int query = q0 + qt * 16 + c;
-            float mx = -INFINITY;
+            float mx = -INFINITY;                          // running maxima are kept on the RAW scores (sc > 0)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int key = kb * 64 + kt * 16 + 4 * g + i;
                     const bool ok = key < a.t && (!a.causal || key <= query);
-                    const float v = ok ? s[kt][qt][i] * sc : -INFINITY;
+                    const float v = ok ? s[kt][qt][i] : -INFINITY;
                     s[kt][qt][i] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -112,14 +150,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * sc);
             m_run[qt] = m_new;
+            const float ms = m_use * sc;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(s[kt][qt][i] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][i], sc, -ms));     // exp2(-inf) = 0 for masked keys
                     ps += p;
                     pf[qt][kt >> 1][(kt & 1) * 4 + i] = (half_t)p;
                 }

@@ -391,6 +391,10 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
         // decode scratch in x-fragment form: lanes of unused batch rows must hold finite values forever
         CK(hipMemsetAsync(ctx->d_attn, 0, (size_t)rup(g.max_batch, 16) * g.llm_hidden * 2, s));
         CK(hipMemsetAsync(ctx->d_h, 0, (size_t)rup(g.max_batch, 16) * g.llm_mlp * 2, s));
+        // KV pool: attention reads whole 64-token pages and weights the not-yet-written tail of the last page with p = 0;
+        // 0 x (stale bits that decode as NaN / Inf) would poison the output, so the pool starts all-zero and from then on
+        // only finite K / V values are ever stored into it.
+        CK(hipMemsetAsync(ctx->kvpool, 0, (size_t)ctx->kv_bytes, s));
         CK(hipStreamSynchronize(s));
     }
     if (!have_vit && !have_llm) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: no weights were provided");
