@@ -18,7 +18,10 @@ SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "norm.hip", "tom
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # tome.hip carries the bit-exact fp32 contract: no implicit FMA contraction
 # preprocess.hip computes Pillow's resampling taps in doubles on the host: same rule
-PER_FILE = {"tome.hip": ["-ffp-contract=off"], "preprocess.hip": ["-ffp-contract=off"]}
+# attn.hip rescales its output accumulators every key block: keep them in VGPRs (MFMA VGPR form) instead of paying
+# 224 v_accvgpr_read/write per block for the AGPR round trip
+PER_FILE = {"tome.hip": ["-ffp-contract=off"], "preprocess.hip": ["-ffp-contract=off"],
+            "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:

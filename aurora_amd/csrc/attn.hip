@@ -132,20 +132,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             }
         }
         h8 pf[2][2];
+        // wave-uniform: unless every key of this block is valid for every query of this wave, mask first (diagonal / last block)
+        if (!((kb * 64 + 63 < a.t) && (!a.causal || kb * 64 + 63 <= q0))) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int query = q0 + qt * 16 + c;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = kb * 64 + kt * 16 + 4 * g + i;
+                        const bool ok = key < a.t && (!a.causal || key <= query);
+                        s[kt][qt][i] = ok ? s[kt][qt][i] : -INFINITY;
+                    }
+            }
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int query = q0 + qt * 16 + c;
             float mx = -INFINITY;                          // running maxima are kept on the RAW scores (sc > 0)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = kb * 64 + kt * 16 + 4 * g + i;
-                    const bool ok = key < a.t && (!a.causal || key <= query);
-                    const float v = ok ? s[kt][qt][i] : -INFINITY;
-                    s[kt][qt][i] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][qt][i]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
