@@ -680,16 +680,19 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __rest
     if (tok == 0x7fffffff) tok = 0;
     __syncthreads();
     if (tid == 0) {
-        if (!finished[b]) {
+        const bool was_finished = finished[b] != 0;
+        if (!was_finished) {
             const int n = out_len[b];
             if (n < max_new) {
                 out_ids[(int64_t)b * max_new + n] = tok;
                 out_len[b] = n + 1;
             }
-            if (tok == eos_id) finished[b] = 1;
+            if (tok == eos_id || n + 1 >= max_new) finished[b] = 1;     // EOS, or the output row is full
         }
         if (set_pos >= 0) pos[b] = set_pos;
-        if (advance_pos) pos[b] += 1;
+        // a finished (or idle) slot stops advancing: it keeps recomputing one position inside its own pages, so extra
+        // decode steps (other slots still running, continuous batching) can never walk it past its KV allocation
+        if (advance_pos && !was_finished) pos[b] += 1;
     }
     float ss = 0.f;
     for (int cidx = tid; cidx < (d >> 3); cidx += 256) {

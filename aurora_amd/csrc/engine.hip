@@ -979,6 +979,36 @@ extern "C" int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream) {
     *count_host = n;
     return AUR_OK;
 }
+// ---- per-slot control for continuous batching: slots of the active batch are independent sequences
+static int slot_check(aur_ctx* ctx, int32_t slot, const char* who) {
+    if (ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "%s: no active batch (aur_begin_batch)", who);
+    if (slot < 0 || slot >= ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "%s: slot %d outside the batch of %d", who, slot, ctx->batch);
+    return AUR_OK;
+}
+extern "C" int aur_slot_reset(aur_ctx* ctx, int32_t slot, void* stream) {
+    if (int rc = slot_check(ctx, slot, "aur_slot_reset")) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CK(hipMemsetAsync(ctx->s_len + slot, 0, 4, s));
+    CK(hipMemsetAsync(ctx->s_fin + slot, 0, 4, s));
+    CK(hipMemsetAsync(ctx->s_pos + slot, 0, 4, s));
+    CK(hipMemsetAsync(ctx->s_ids + (int64_t)slot * ctx->max_new, 0, (size_t)ctx->max_new * 4, s));
+    return AUR_OK;
+}
+extern "C" int aur_slot_retire(aur_ctx* ctx, int32_t slot, void* stream) {
+    if (int rc = slot_check(ctx, slot, "aur_slot_retire")) return rc;
+    const int32_t one = 1;
+    CK(hipMemcpyAsync(ctx->s_fin + slot, &one, 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    CK(hipStreamSynchronize((hipStream_t)stream));          // `one` lives on this stack frame
+    return AUR_OK;
+}
+extern "C" int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, void* stream) {
+    if (ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "aur_slot_state: no active batch");
+    hipStream_t s = (hipStream_t)stream;
+    if (lens_host) CK(hipMemcpyAsync(lens_host, ctx->s_len, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
+    if (finished_host) CK(hipMemcpyAsync(finished_host, ctx->s_fin, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    return AUR_OK;
+}
 extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
     if (ctx->batch < 1 || !dst_dev) return aur_fail(ctx, AUR_ERR_STATE, "aur_copy_logits: no active batch");
     CK(hipMemcpyAsync(dst_dev, ctx->d_logits, (size_t)ctx->batch * ctx->cfg.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -447,6 +447,61 @@ class AuroraCapEngine:
                 break
         return self.outputs()
 
+    # ------------------------------------------------------------------ continuous batching
+    def slot_reset(self, slot: int):
+        check(self.ctx, self.L.aur_slot_reset(self.ctx, slot, self._stream()), "aur_slot_reset")
+
+    def slot_retire(self, slot: int):
+        check(self.ctx, self.L.aur_slot_retire(self.ctx, slot, self._stream()), "aur_slot_retire")
+
+    def slot_state(self):
+        lens = np.zeros(self._batch, np.int32)
+        fin = np.zeros(self._batch, np.int32)
+        check(self.ctx, self.L.aur_slot_state(self.ctx, lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              fin.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "aur_slot_state")
+        return lens, fin
+
+    def caption_stream(self, clips, token_kept_ratio: float, max_new_tokens: int, eos_id: Optional[int] = 2, slots: Optional[int] = None,
+                       check_every: int = 16):
+        """Continuous batching over an iterable of (pixel_values, input_ids): up to `slots` (default max_batch) captions are
+        in flight; every `check_every` decode steps the finished slots are collected and re-filled with the next clips
+        (ViT + projector + prefill into the free slot while the others keep their KV and state).  Yields (index, ids) in
+        completion order; each clip's ids equal what it produces alone (batch-invariant kernels)."""
+        B = self.max_batch if slots is None else slots
+        if not 1 <= B <= self.max_batch:
+            raise ValueError(f"slots={B} for an engine built with max_batch={self.max_batch}")
+        self.begin_batch(B, max_new_tokens, eos_id)
+        for s in range(B):
+            self.slot_retire(s)
+        it = iter(enumerate(clips))
+        owner: List[Optional[int]] = [None] * B
+        exhausted = False
+        while True:
+            for s in range(B):                                    # fill every free slot
+                if owner[s] is not None or exhausted:
+                    continue
+                nxt = next(it, None)
+                if nxt is None:
+                    exhausted = True
+                    break
+                idx, (px, ids) = nxt
+                r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
+                vis = self.vit_encode(px, r)
+                emb, L = self.project_splice(vis, list(ids))
+                self.slot_reset(s)
+                self.prefill(s, emb, L)
+                owner[s] = idx
+            if all(o is None for o in owner):
+                return
+            self.decode(check_every)
+            lens, fin = self.slot_state()
+            done = [s for s in range(B) if owner[s] is not None and fin[s]]
+            if done:
+                out = self.outputs()
+                for s in done:
+                    yield owner[s], out[s]
+                    owner[s] = None
+
     # ------------------------------------------------------------------ kernel-level entry points (tests)
     def tome_step(self, metric: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], r: int):
         F, t, c = metric.shape

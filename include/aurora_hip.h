@@ -128,6 +128,14 @@ int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream);
 int aur_get_outputs(aur_ctx* ctx, int32_t* ids_host, int32_t* lens_host, void* stream);
 /* Synchronises; number of slots still generating (EOS not seen, length < max_new_tokens). */
 int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream);
+/* Continuous batching: the slots of the active batch are independent sequences.  A slot is
+ * finished after EOS or max_new_tokens; a finished slot stops advancing (it never leaves its KV pages however many more
+ * steps the batch decodes).  aur_slot_reset makes a slot empty and active again - follow it with aur_llm_prefill into
+ * that slot while the other slots keep their state; aur_slot_retire parks a slot (finished, nothing to collect);
+ * aur_slot_state copies the per-slot generated lengths / finished flags to the host (synchronises the stream). */
+int aur_slot_reset(aur_ctx* ctx, int32_t slot, void* stream);
+int aur_slot_retire(aur_ctx* ctx, int32_t slot, void* stream);
+int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, void* stream);
 
 /* ---- kernel-level entry points (parity tests, reuse by other callers) --------------------------- */
 /* One ToMe step on caller data: replaces bipartite_soft_matching + merge_wavg (tome.py:18-98,207-219;

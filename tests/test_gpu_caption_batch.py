@@ -95,3 +95,37 @@ def test_lmms_adaptor_on_real_engine():
             assert texts[i] == " ".join(map(str, want)), i
     finally:
         eng.close()
+
+
+def test_caption_stream_continuous_batching():
+    """11 ragged clips through 4 slots with EOS stopping: finished slots are re-filled while the others keep decoding;
+    every clip must get exactly the ids it gets alone, and a finished slot must not disturb its neighbours."""
+    eng = build(max_batch=4, max_new=24)
+    try:
+        cs = clips(11, 9)
+        alone_full = [eng.caption_ids(px, ids, 0.5, 24, eos_id=None) for px, ids in cs]
+        eos = alone_full[2][5]                                      # an id that really occurs -> ragged stopping times
+        want = [a[: a.index(eos) + 1] if eos in a else a for a in alone_full]
+        assert len({len(w) for w in want}) > 1
+        got = dict(eng.caption_stream(cs, 0.5, 24, eos_id=eos, check_every=4))
+        assert sorted(got) == list(range(11))
+        for i in range(11):
+            assert got[i] == want[i], i
+        # fewer clips than slots, slots < max_batch, no EOS
+        got = dict(eng.caption_stream(cs[:2], 0.5, 7, eos_id=None, slots=3, check_every=16))
+        assert got == {0: alone_full[0][:7], 1: alone_full[1][:7]}
+        assert list(eng.caption_stream([], 0.5, 7)) == []
+        # decoding far past the end of every sequence must be harmless (positions freeze at the last token)
+        eng.begin_batch(2, 6, None)
+        for b in range(2):
+            vis = eng.vit_encode(cs[b][0], eng.tome_r(0.5))
+            emb, L = eng.project_splice(vis, cs[b][1])
+            eng.prefill(b, emb, L)
+        eng.decode(200)
+        assert eng.outputs() == [alone_full[0][:6], alone_full[1][:6]]
+        lens, fin = eng.slot_state()
+        assert lens.tolist() == [6, 6] and fin.tolist() == [1, 1]
+        with pytest.raises(Exception):
+            eng.slot_reset(2)
+    finally:
+        eng.close()
