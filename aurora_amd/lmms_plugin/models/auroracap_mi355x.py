@@ -228,36 +228,44 @@ class AuroraCapMI355X(_Base):
         return np.stack([x.to_ndarray(format="rgb24") for x in frames])
 
     # ---- generate_until ---------------------------------------------------------------------------------------------
+    def _clip(self, args) -> tuple:
+        """One request -> (pixel_values [f, 3, R, R] fp16 on the device, input ids with -200 markers)."""
+        context, _, doc_to_visual, doc_id, task, split = args
+        visuals = self.flatten([doc_to_visual(self.task_dict[task][split][doc_id])])
+        if not visuals:
+            raise NotImplementedError("text-only requests: the AuroraCap path needs at least one frame")
+        frames = self.load_frames(visuals)
+        pixel_values = self._pre(torch.from_numpy(np.ascontiguousarray(frames)).to(self._device))
+        prompt = conv_prompt(question_with_image_tokens(context, len(frames)), self.conv_template)
+        return pixel_values, tokenizer_image_token(prompt, self._tokenizer, IMAGE_TOKEN_INDEX)
+
     def generate_until(self, requests) -> List[str]:
         args_list = [r.args for r in requests]
         res: List[Optional[str]] = [None] * len(args_list)
-        for batch in plan_batches(args_list, lambda s: len(self.tok_encode(s)), self.batch_size):
+
+        def deliver(i, ids, gen):
+            res[i] = self._tokenizer.batch_decode([ids], skip_special_tokens=True)[0]
+            if self.cache_hook is not None:
+                self.cache_hook.add_partial("generate_until", (args_list[i][0], gen), [res[i]])
+
+        stream = hasattr(self._model, "caption_stream") and not self.slowfast
+        # with continuous batching a whole generation-kwargs group is one stream (clips are decoded / preprocessed lazily,
+        # finished KV slots are re-filled); otherwise the group is cut into chunks of batch_size like the reference does
+        for batch in plan_batches(args_list, lambda s: len(self.tok_encode(s)), len(args_list) if stream else self.batch_size):
             gen = gen_defaults(args_list[batch[0]][1])
-            clips = []
-            for i in batch:
-                context, _, doc_to_visual, doc_id, task, split = args_list[i]
-                visuals = self.flatten([doc_to_visual(self.task_dict[task][split][doc_id])])
-                if visuals:
-                    frames = self.load_frames(visuals)
-                    pixel_values = self._pre(torch.from_numpy(np.ascontiguousarray(frames)).to(self._device))
-                    n_img = len(frames)
-                else:
-                    raise NotImplementedError("text-only requests: the AuroraCap path needs at least one frame")
-                prompt = conv_prompt(question_with_image_tokens(context, n_img), self.conv_template)
-                clips.append((pixel_values, tokenizer_image_token(prompt, self._tokenizer, IMAGE_TOKEN_INDEX)))
             self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)
-            if self.slowfast:                   # ragged per-frame token counts: one clip at a time through the three calls
-                ids = []
-                for px, tok_ids in clips:
+            if stream:
+                for k, ids in self._model.caption_stream((self._clip(args_list[i]) for i in batch), max_new_tokens=gen["max_new_tokens"]):
+                    deliver(batch[k], ids, gen)
+            elif self.slowfast:                 # ragged per-frame token counts: one clip at a time through the three calls
+                for i in batch:
+                    px, tok_ids = self._clip(args_list[i])
                     self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)     # the slow-fast forward leaves it at 1.0
                     out = self._model({"pixel_values": px.unsqueeze(0), "input_ids": torch.tensor([tok_ids])}, mode="inference")
-                    ids.append(self._model.llm.generate(**out, do_sample=False, num_beams=1,
-                                                        max_new_tokens=gen["max_new_tokens"])[0].tolist())
+                    deliver(i, self._model.llm.generate(**out, do_sample=False, num_beams=1,
+                                                        max_new_tokens=gen["max_new_tokens"])[0].tolist(), gen)
             else:
-                ids = self._model.caption_batch(clips, max_new_tokens=gen["max_new_tokens"])
-            texts = self._tokenizer.batch_decode(ids, skip_special_tokens=True)
-            for i, text in zip(batch, texts):
-                res[i] = text
-                if self.cache_hook is not None:
-                    self.cache_hook.add_partial("generate_until", (args_list[i][0], gen), [text])
+                ids = self._model.caption_batch([self._clip(args_list[i]) for i in batch], max_new_tokens=gen["max_new_tokens"])
+                for i, x in zip(batch, ids):
+                    deliver(i, x, gen)
         return res
