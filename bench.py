@@ -285,11 +285,11 @@ def main():
                                     % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
                        "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
                        "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
-                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G,
+                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G, "vit_chunk": VC,
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
-            "ttft_note": "time from the start of a batch's front end (ViT for all its clips first) to each clip's first token, batch of %d clips"
-                         % B + ("; the front end shares the GPU with the previous batch's decode" if pipe else ""),
+            "ttft_note": "time from the start of a batch's front end to each clip's first token, batch of %d clips (ViT in chunks of %d clips, "
+                         "prefill in groups of %d)" % (B, VC, G) + ("; the front end shares the GPU with the previous batch's decode" if pipe else ""),
         }
 
     # ---- instrumented pass (rank 0, after the timed region, not pipelined): HIP events per stage and around the
