@@ -223,10 +223,14 @@ def main():
             step()
         fence()
         t_start = time.perf_counter()
+        outs = []
         for _ in range(args.steps):
             out = step(True)
+            outs.append(out)
         fence()
         elapsed = time.perf_counter() - t_start
+        # every step captions the same synthetic clips: the ids must repeat exactly (a race or a stale buffer would show)
+        assert all(o == outs[0] for o in outs), "generated ids differ between identical steps"
     else:
         sD = torch.cuda.current_stream()                           # the engine's stream: decode
         sP = torch.cuda.Stream()                                   # front end of the next batch
