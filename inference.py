@@ -22,15 +22,18 @@ from aurora_amd.preprocess import read_video_pyav  # noqa: E402  (frame sampling
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument('--model_path', type=str, help='path to the model', default='wchai/AuroraCap-7B-IMG-xtuner')
-    parser.add_argument('--prompt', type=str, help='prompt for the model', default='Describe the video in detail.')
-    parser.add_argument('--visual_input', type=str, help='path to the video or image file', default='output.png')
-    parser.add_argument('--num_frm', type=int, help='number of frames to sample from the video', default=8)
-    parser.add_argument('--token_kept_ratio', type=float, help='token merge ratio', default=0.8)
-    parser.add_argument('--temperature', type=float, help='temperature', default=0.0)
-    parser.add_argument('--top_p', type=float, help='top p', default=1.0)
-    parser.add_argument('--num_beams', type=int, help='number of beams', default=1)
-    parser.add_argument('--max_new_tokens', type=int, help='max new tokens', default=2048)
+    # the reference CLI's argument surface (inference.py:31-40): same flags, types and defaults
+    for flag, typ, default, text in (
+            ("model_path", str, "wchai/AuroraCap-7B-IMG-xtuner", "checkpoint directory (xtuner layout) or hub id"),
+            ("prompt", str, "Describe the video in detail.", "instruction given to the model"),
+            ("visual_input", str, "output.png", "video (.mp4) or image (.png / .jpg) file"),
+            ("num_frm", int, 8, "frames sampled uniformly from a video"),
+            ("token_kept_ratio", float, 0.8, "fraction of visual tokens kept by the per-layer token merge"),
+            ("temperature", float, 0.0, "sampling temperature (greedy only on this path)"),
+            ("top_p", float, 1.0, "nucleus mass (unused: greedy)"),
+            ("num_beams", int, 1, "beam count (only 1 is implemented)"),
+            ("max_new_tokens", int, 2048, "generation budget")):
+        parser.add_argument("--" + flag, type=typ, default=default, help=text)
     parser.add_argument('--host_preprocess', action='store_true', help='resize/normalise on the host with CLIPImageProcessor (PIL) instead of the HIP input stage')
     parser.add_argument('--synthetic', action='store_true', help='seeded synthetic weights / clip / prompt ids (no checkpoint needed)')
     args = parser.parse_args()
