@@ -20,7 +20,7 @@ import torch
 from aurora_amd.preprocess import read_video_pyav  # noqa: E402  (frame sampling contract of load_video.py:31-71)
 
 
-def main():
+def build_parser() -> argparse.ArgumentParser:
     parser = argparse.ArgumentParser()
     # the reference CLI's argument surface (inference.py:31-40): same flags, types and defaults
     for flag, typ, default, text in (
@@ -36,7 +36,11 @@ def main():
         parser.add_argument("--" + flag, type=typ, default=default, help=text)
     parser.add_argument('--host_preprocess', action='store_true', help='resize/normalise on the host with CLIPImageProcessor (PIL) instead of the HIP input stage')
     parser.add_argument('--synthetic', action='store_true', help='seeded synthetic weights / clip / prompt ids (no checkpoint needed)')
-    args = parser.parse_args()
+    return parser
+
+
+def main():
+    args = build_parser().parse_args()
     if args.num_beams != 1:
         sys.exit("error: only greedy decoding is implemented on the MI355X path (--num_beams 1)")
 

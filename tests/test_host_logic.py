@@ -110,3 +110,25 @@ def test_gather_results_gloo_world2():
         assert p.exitcode == 0
     want = [[c * 10 + k for k in range(1 + (c % 6))] for c in range(5)]
     assert res[0] == want and res[1] == want
+
+
+def test_cli_argument_surface_matches_reference():
+    """inference.py keeps the reference CLI's flags, types and defaults (reference inference.py:31-40), so existing
+    command lines run unchanged; unknown flags are rejected; beams > 1 exits with a message."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "inference.py", "--help"], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--model_path", "--prompt", "--visual_input", "--num_frm", "--token_kept_ratio", "--temperature", "--top_p",
+                 "--num_beams", "--max_new_tokens"):
+        assert flag in out.stdout, flag
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("inference_cli", os.path.join(root, "inference.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = mod.build_parser().parse_args([])
+    assert (args.model_path, args.prompt, args.visual_input) == ("wchai/AuroraCap-7B-IMG-xtuner", "Describe the video in detail.", "output.png")
+    assert (args.num_frm, args.token_kept_ratio, args.temperature, args.top_p, args.num_beams, args.max_new_tokens) == (8, 0.8, 0.0, 1.0, 1, 2048)
+    bad = subprocess.run([sys.executable, "inference.py", "--num_beams", "4"], cwd=root, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "greedy" in (bad.stderr + bad.stdout)
