@@ -2,6 +2,7 @@
 """Summarise rocprofv3 output directories into small text files kept under profiles/.
 
   kernel stats : <dir>/**/**kernel_stats.csv  -> top kernels by total time (calls, avg us, %)
+  kernel shapes: <dir>/**/**kernel_trace.csv  -> the same per (kernel, grid size)
   pmc counters : <dir>/**/**counter_collection.csv -> per-kernel mean of each counter
 """
 import csv
@@ -29,6 +30,24 @@ def kernel_stats(d, out):
                   f"{float(r['TotalDurationNs']) / 1e6:10.2f} {100 * float(r['TotalDurationNs']) / tot:6.2f}\n")
 
 
+def kernel_shapes(d, out):
+    """Per-launch trace grouped by (kernel, grid): separates the GEMM shapes that share one kernel name."""
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        out.write("no kernel_trace.csv found\n")
+        return
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(files[0])):
+        grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        a = acc[(r["Kernel_Name"], grid)]
+        a[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        a[1] += 1
+    tot = sum(v[0] for v in acc.values())
+    out.write(f"# {files[0]}\n{'kernel':80s} {'grid (threads)':>18s} {'calls':>7s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}\n")
+    for (k, g), (ns, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:40]:
+        out.write(f"{short(k, 80):80s} {g:>18s} {n:7d} {ns / n / 1e3:10.2f} {ns / 1e6:10.2f} {100 * ns / tot:6.2f}\n")
+
+
 def pmc(d, out):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -52,5 +71,5 @@ def pmc(d, out):
 if __name__ == "__main__":
     mode, d, dst = sys.argv[1], sys.argv[2], sys.argv[3]
     with open(dst, "w") as out:
-        (kernel_stats if mode == "stats" else pmc)(d, out)
+        {"stats": kernel_stats, "shapes": kernel_shapes}.get(mode, pmc)(d, out)
     print(open(dst).read()[:6000])
