@@ -48,9 +48,6 @@ def parse():
     p.add_argument("--pipeline", action="store_true",
                    help="overlap batch i's decode with batch i+1's ViT + prefill on two streams / two KV banks "
                         "(measured on MI355X: +2-3 %% captions/s, +37 %% p50 TTFT - off by default)")
-    p.add_argument("--cu-front", type=int, default=0,
-                   help="with --pipeline: give the front end (ViT + prefill) this many dedicated CUs and decode the rest "
-                        "(CU-masked streams); 0 = both streams may use every CU")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,27 +234,6 @@ def main():
     else:
         sD = torch.cuda.current_stream()                           # the engine's stream: decode
         sP = torch.cuda.Stream()                                   # front end of the next batch
-        if args.cu_front > 0:
-            # dedicated CUs per stage (hipExtStreamCreateWithCUMask): the MFMA-bound front end and the HBM-bound decode stop
-            # competing for the same CUs / LDS.  CUs are dealt out evenly (Bresenham), so both masks cover every XCD.
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            ncu = torch.cuda.get_device_properties(local).multi_processor_count
-            take = [((i + 1) * args.cu_front) // ncu > (i * args.cu_front) // ncu for i in range(ncu)]
-
-            def masked_stream(bits):
-                words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
-                for i, on in enumerate(bits):
-                    if on:
-                        words[i // 32] |= 1 << (i % 32)
-                h = ctypes.c_void_p()
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(words), words)
-                assert rc == 0, f"hipExtStreamCreateWithCUMask failed ({rc})"
-                return torch.cuda.ExternalStream(h.value, device=dev)
-            sP = masked_stream(take)
-            sDm = masked_stream([not t for t in take])
-            sDm.wait_stream(sD)
-            sD = sDm
         sP.wait_stream(sD)
         ev_front = [None, None]
         ev_back = [None, None]
@@ -273,11 +249,10 @@ def main():
                 ev_front[bank ^ 1].record(sP)
                 if record_ttft:
                     pending.append((ev0, evs))
-            with torch.cuda.stream(sD):
-                sD.wait_event(ev_front[bank])                      # batch i was prefetched one iteration ago
-                o = back(bank)
-                ev_back[bank] = torch.cuda.Event()
-                ev_back[bank].record(sD)
+            sD.wait_event(ev_front[bank])                          # batch i was prefetched one iteration ago
+            o = back(bank)
+            ev_back[bank] = torch.cuda.Event()
+            ev_back[bank].record(sD)
             return o
 
         with torch.cuda.stream(sP):                                # prime: front end of batch 0
