@@ -1020,6 +1020,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
+    else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);
 
     else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {

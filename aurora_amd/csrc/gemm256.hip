@@ -172,9 +172,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     const int nbn = a.Npad >> 8;
     const int nbm = (a.M + 255) >> 8;
     const int nwg = nbn * nbm;
+    // Persistent mode (gemm256_set_max_wgs): a fixed number of workgroups walks the tiles, so the GEMM occupies only that many
+    // CUs (one 160 KiB workgroup per CU) and leaves the others to a concurrently running stream.  gridDim.x is a multiple of 8
+    // there, so a workgroup's tiles keep the XCD (bid % 8) the remap assumes.  Default: one workgroup per tile.
+    for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
     int lid;
     {   // XCD-aware bijective remap (guide T1)
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+        const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
         lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     }
     // super-rows of 4 M-tiles, column-major inside: an XCD's 32 consecutive tiles are 4 (M) x 8 (N), so every weight
@@ -193,6 +197,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     if (vmode) g2_mainloop<EPI, true>(a, smem, acc, bm, bn, w, lane);
     else g2_mainloop<EPI, false>(a, smem, acc, bm, bn, w, lane);
     gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
+    __syncthreads();                              // the next tile's prologue refills LDS
+    }
 }
 
 hipError_t gemm256_init() {
@@ -208,8 +214,13 @@ bool gemm256_eligible(const GemmArgs& a) {
     return tiles >= 224;
 }
 
+static int g_gemm256_max_wgs = 0;
+void gemm256_set_max_wgs(int n) { g_gemm256_max_wgs = n > 0 ? (n + 7) & ~7 : 0; }
+
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
-    dim3 grid((a.Npad >> 8) * ((a.M + 255) >> 8)), block(512);
+    int ntiles = (a.Npad >> 8) * ((a.M + 255) >> 8);
+    if (g_gemm256_max_wgs > 0 && ntiles > g_gemm256_max_wgs) ntiles = g_gemm256_max_wgs;
+    dim3 grid(ntiles), block(512);
     if (epi == EPI_ROW) hipLaunchKernelGGL(gemm256_kernel<EPI_ROW>, grid, block, G2_LDS, s, a);
     else hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, grid, block, G2_LDS, s, a);
     return hipGetLastError();

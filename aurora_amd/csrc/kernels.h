@@ -39,6 +39,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 hipError_t gemm256_init();
 bool gemm256_eligible(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
+void gemm256_set_max_wgs(int n);  // > 0: persistent 256x256 GEMM on at most n workgroups (= CUs); 0: one workgroup per tile
 void gemm_set_mode(int mode);      // 0: 128x128 kernel only, 1: auto (default), 2: force 256 when Npad % 256 == 0
 hipError_t launch_pack_weight(const half_t* w, int n_src, int k_src, int ld_src, const int32_t* row_map, int npad,
                               int kpad, half_t* out, hipStream_t s);

@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--pipeline", action="store_true",
                    help="overlap batch i's decode with batch i+1's ViT + prefill on two streams / two KV banks "
                         "(measured on MI355X: +2-3 %% captions/s, +37 %% p50 TTFT - off by default)")
+    p.add_argument("--gemm-cus", type=int, default=0,
+                   help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
+                        "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,6 +158,8 @@ def main():
     torch.cuda.empty_cache()
     if args.gemm_mode >= 0:
         eng.set_option("gemm_mode", args.gemm_mode)
+    if args.gemm_cus > 0:
+        eng.set_option("gemm_max_wgs", args.gemm_cus)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B

@@ -216,3 +216,21 @@ def test_gemm256_equals_gemm128_bitwise_per_element_order(eng):
     o256 = eng.linear(a, w, None)
     eng.set_option("gemm_mode", 1)
     assert torch.equal(o128, o256)
+
+
+def test_gemm256_persistent_tiles_bitwise(eng):
+    """gemm_max_wgs: a fixed number of workgroups walks all 256x256 tiles (used to confine the GEMM to a CU subset when
+    two streams share the GPU) - results must not change by a bit, ragged M included."""
+    g = torch.Generator().manual_seed(100)
+    a = (torch.randn(3000, 1280, generator=g) * 0.5).half()
+    w = (torch.randn(2560, 1280, generator=g) * 0.05).half()
+    b = (torch.randn(2560, generator=g) * 0.1).half()
+    eng.set_option("gemm_mode", 2)
+    try:
+        ref = eng.linear(a, w, b)                                    # 12 x 10 tiles, one workgroup each
+        for n in (8, 16, 24, 112):
+            eng.set_option("gemm_max_wgs", n)
+            assert torch.equal(eng.linear(a, w, b), ref), n
+    finally:
+        eng.set_option("gemm_max_wgs", 0)
+        eng.set_option("gemm_mode", 1)
