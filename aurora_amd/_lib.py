@@ -24,7 +24,7 @@ class AurConfig(C.Structure):
         ("llm_vocab", C.c_int32),
         ("llm_rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_factor", C.c_float),
         ("max_frames", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32),
-        ("page_tokens", C.c_int32), ("use_graph", C.c_int32), ("num_banks", C.c_int32),
+        ("page_tokens", C.c_int32), ("use_graph", C.c_int32), ("num_banks", C.c_int32), ("vit_native_image", C.c_int32),
     ]
 
 

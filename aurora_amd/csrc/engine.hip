@@ -47,7 +47,7 @@ struct aur_ctx {
     int64_t kv_bytes = 0;
     bool finalized = false;
     // derived: vision
-    int v_hd, v_hd_pad, v_kblk, v_vd16, v_qcols, v_qkv_npad, v_dpad, v_mlp_pad, v_npatch, v_t0, v_t0pad, v_kpad;
+    int v_hd, v_hd_pad, v_kblk, v_vd16, v_qcols, v_qkv_npad, v_dpad, v_mlp_pad, v_npatch, v_t0, v_t0pad, v_kpad, v_native_npatch;
     // derived: llm
     int l_hd, l_kblk, l_vd16, l_qkv_npad, l_gu_npad, l_dpad, l_vocab_pad, l_max_pages, l_ctx_pad;
     int64_t l_page_halves, l_layer_halves;
@@ -162,6 +162,8 @@ static void derive(aur_ctx* c) {
     c->v_npatch = gw * gw;
     c->v_t0 = c->v_npatch + 1;
     c->v_t0pad = rup(c->v_t0, 32);
+    const int gn = (g.vit_native_image > 0 ? g.vit_native_image : g.vit_image) / g.vit_patch;    // grid of the checkpoint's position table
+    c->v_native_npatch = gn * gn;
     c->v_kpad = rup(g.vit_channels * g.vit_patch * g.vit_patch, 64);
     c->l_hd = g.llm_hidden / g.llm_heads;
     c->l_kblk = c->l_hd / 32;
@@ -253,6 +255,8 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
     if (g.max_batch < 1 || g.max_batch > AUR_MAX_BATCH) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, %d]", AUR_MAX_BATCH);
     if (g.page_tokens < 64 || g.page_tokens % 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be a multiple of 64");
     if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
+    if (g.vit_native_image < 0 || g.vit_native_image > g.vit_image || g.vit_native_image % g.vit_patch)
+        return aur_fail(nullptr, AUR_ERR_ARG, "vit_native_image must be 0 or a multiple of the patch size <= vit_image");
     {
         hipError_t e;
         if ((e = gemm_init()) != hipSuccess || (e = attn_init()) != hipSuccess || (e = tome_init()) != hipSuccess ||
@@ -334,7 +338,7 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
     if (have_vit) {
         const int64_t D = g.vit_hidden;
         bool ok = get(ctx, "vit.patch.w", &ctx->v_patch_w, (int64_t)ctx->v_dpad * ctx->v_kpad * 2) &&
-                  get(ctx, "vit.cls", &ctx->v_cls, D * 2) && get(ctx, "vit.pos", &ctx->v_pos, (int64_t)ctx->v_t0 * D * 2) &&
+                  get(ctx, "vit.cls", &ctx->v_cls, D * 2) && get(ctx, "vit.pos", &ctx->v_pos, (int64_t)(ctx->v_native_npatch + 1) * D * 2) &&
                   get(ctx, "vit.preln.w", &ctx->v_preln_w, D * 4) && get(ctx, "vit.preln.b", &ctx->v_preln_b, D * 4);
         if (!ok) return AUR_ERR_STATE;
         // hidden_states[-2] needs layers 0 .. L-2 only: the last layer's weights are optional
@@ -577,7 +581,7 @@ extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frame
     if (gh < 1 || gw < 1 || t0 > ctx->v_t0)
         return aur_fail(ctx, AUR_ERR_ARG, "input %dx%d gives %d tokens per frame; this ctx holds up to %d (vit_image %d)", height, width,
                         t0, ctx->v_t0, g.vit_image);
-    const bool native = gh == gw && npatch == ctx->v_npatch;
+    const bool native = gh == gw && npatch == ctx->v_native_npatch;
     if (!pos_emb && !native) return aur_fail(ctx, AUR_ERR_ARG, "a %dx%d patch grid needs an interpolated position table (pos_emb)", gh, gw);
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "vit", s);
@@ -616,7 +620,8 @@ extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frame
 
 extern "C" int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, void* out_tokens,
                               int32_t* n_kept_out, void* stream) {
-    return aur_vit_encode_hw(ctx, pixels, frames, ctx->cfg.vit_image, ctx->cfg.vit_image, nullptr, r, out_tokens, n_kept_out, stream);
+    const int nat = ctx->cfg.vit_native_image > 0 ? ctx->cfg.vit_native_image : ctx->cfg.vit_image;
+    return aur_vit_encode_hw(ctx, pixels, frames, nat, nat, nullptr, r, out_tokens, n_kept_out, stream);
 }
 
 extern "C" int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size, int32_t frames, int32_t t,

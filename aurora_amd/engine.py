@@ -38,7 +38,7 @@ def tokens_at_layer(t0: int, r: int, layer: int) -> int:
 class AuroraCapEngine:
     def __init__(self, cfg: dict, weights: dict, *, max_frames: int = 8, max_batch: int = 1, max_ctx: int = 4096,
                  max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, num_banks: int = 1,
-                 device: str = "cuda:0"):
+                 max_image: Optional[int] = None, device: str = "cuda:0"):
         if not torch.cuda.is_available():
             raise _lib.AuroraHipError("AuroraCapEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback")
@@ -61,7 +61,11 @@ class AuroraCapEngine:
         ll = l or dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=128, vocab_size=128,
                        rms_norm_eps=1e-5, rope_theta=1e4)
         c.vit_hidden, c.vit_heads, c.vit_layers = vv["hidden_size"], vv["num_attention_heads"], vv["num_hidden_layers"]
-        c.vit_mlp, c.vit_patch, c.vit_image = vv["intermediate_size"], vv["patch_size"], vv["image_size"]
+        # vit_image is the CAPACITY (largest input side the workspace admits); the checkpoint's position table belongs to
+        # image_size.  max_image > image_size admits larger inputs through the interpolated table (aurora.py:909-951).
+        self.max_image = max(int(max_image or 0), vv["image_size"]) // vv["patch_size"] * vv["patch_size"]
+        c.vit_mlp, c.vit_patch, c.vit_image = vv["intermediate_size"], vv["patch_size"], self.max_image
+        c.vit_native_image = vv["image_size"]
         c.vit_channels = vv.get("num_channels", 3)
         act = vv.get("hidden_act", "quick_gelu")
         if act not in ("quick_gelu", "gelu"):
@@ -266,9 +270,9 @@ class AuroraCapEngine:
         px = self._h(pixels)
         F, H, W = px.shape[0], px.shape[-2], px.shape[-1]
         t0 = (H // v["patch_size"]) * (W // v["patch_size"]) + 1
-        if t0 < 2 or t0 > (v["image_size"] // v["patch_size"]) ** 2 + 1:
+        if t0 < 2 or t0 > (self.max_image // v["patch_size"]) ** 2 + 1:
             raise ValueError(f"a {H}x{W} input has {t0} tokens per frame; this engine holds up to "
-                             f"{(v['image_size'] // v['patch_size']) ** 2 + 1} (image_size {v['image_size']})")
+                             f"{(self.max_image // v['patch_size']) ** 2 + 1} (max_image {self.max_image})")
         n_kept = tokens_at_layer(t0, r, v["num_hidden_layers"] - 1) - 1
         out = torch.empty(F, n_kept, v["hidden_size"], dtype=torch.float16, device=self.dev)
         nk = C.c_int32(0)

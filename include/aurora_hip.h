@@ -53,6 +53,8 @@ typedef struct aur_config {
     int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
     int32_t use_graph;          /* 1: capture the decode step into a hipGraph */
     int32_t num_banks;          /* 1 or 2 generation banks (2: KV pool and per-batch state doubled, see aur_select_bank) */
+    int32_t vit_native_image;   /* side of the square input the checkpoint's position table was trained for (config.image_size);
+                                 * 0 = vit_image.  vit_image is then the CAPACITY: the largest input side aur_vit_encode_hw accepts */
 } aur_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -93,7 +95,7 @@ int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, 
                    int32_t* n_kept_out, void* stream);
 /* Same for inputs that are not vit_image x vit_image (AuroraEncoder.interpolate_pos_encoding,
  * aurora.py:909-951): pixels fp16 [frames, channels, height, width]; the patch grid is (height / patch) x (width / patch)
- * and must fit the ctx ((h/p)*(w/p) + 1 <= (vit_image/patch)^2 + 1).  pos_emb: fp16 [1 + (h/p)*(w/p), vit_hidden], the
+ * and must fit the ctx ((h/p)*(w/p) + 1 <= (vit_image/patch)^2 + 1; make vit_image larger than vit_native_image to admit bigger inputs).  pos_emb: fp16 [1 + (h/p)*(w/p), vit_hidden], the
  * position table the caller interpolated for this grid (bicubic, the reference's scale factors); NULL is allowed only
  * for the native grid.  r is computed by the caller from height and width (aur_tome_r). */
 int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t height, int32_t width,

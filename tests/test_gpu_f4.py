@@ -108,3 +108,28 @@ def test_slowfast_forward_against_oracle():
             m({"pixel_values": px[:, :3], "input_ids": ids}, mode="inference")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("h,w", [(98, 98), (70, 126), (84, 112), (56, 56)])
+def test_inputs_larger_than_the_native_grid(h, w):
+    """max_image decouples the workspace capacity from the checkpoint's position grid: a 56-pixel (4x4) tower encodes
+    98x98 (7x7) or 70x126 (5x9) inputs through the up-sampled position table, like the reference does for any size."""
+    from aurora_amd.engine import AuroraCapEngine
+    cfg = dict(VCFG, image_size=56)
+    wts = rand_vit_weights(cfg, 6)
+    eng = AuroraCapEngine({"vit": cfg, "llm": None}, {"vit": wts}, max_frames=2, max_batch=1, max_ctx=128, max_new_tokens=8, max_image=126)
+    try:
+        px = torch.randn(2, 3, h, w, generator=torch.Generator().manual_seed(h * 3 + w)).half().float()
+        out = eng.vit_encode(px, eng.tome_r(1.0, h, w)).float().cpu()
+        ref = O.vit_features(px, wts, cfg, 1.0)
+        assert out.shape == ref.shape == (2, (h // 14) * (w // 14), 64)
+        assert rel_l2(out, ref) < 5e-3
+        out = eng.vit_encode(px, eng.tome_r(0.4, h, w)).float().cpu()
+        ref = O.vit_features(px, wts, cfg, 0.4, q=O.fp16_storage)
+        # merged case (seeds chosen without a near-tie flip between fp16 storage and fp32: with seed h + w the two ORACLE
+        # variants themselves diverge by 27 % on 70x126 - SURVEY 8c on why index equality is checked per kernel instead)
+        assert out.shape == ref.shape and rel_l2(out.mean(1), ref.mean(1)) < 1e-2
+        with pytest.raises(ValueError):
+            eng.vit_encode(torch.zeros(1, 3, 140, 140), 0)                    # beyond max_image
+    finally:
+        eng.close()
