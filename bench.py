@@ -268,10 +268,13 @@ def main():
             iteration(i, False)
         fence()
         t_start = time.perf_counter()
+        outs = []
         for i in range(args.warmup, args.warmup + args.steps):     # K front ends + K decodes
             out = iteration(i, True)
+            outs.append(out)
         fence()
         elapsed = time.perf_counter() - t_start
+        assert all(o == outs[0] for o in outs), "generated ids differ between identical steps (pipelined banks)"
         for ev0, evs in pending:
             ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
         eng.select_bank(0)
