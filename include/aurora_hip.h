@@ -173,7 +173,10 @@ int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size,
 int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 
 /* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 0/1, "dec_attn_pps" pages per
- * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256). */
+ * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
+ * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
+ * "microbench_prefill_nseq" sequences per pass for the pre_* microbenchmarks.  The gemm_* knobs are bit-neutral; the
+ * dec_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
 /* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
  * kernel in {dec_norm, dec_qkv, dec_attn, dec_o, dec_gateup, dec_down, dec_lm_head, pre_norm, pre_qkv, pre_attn,
