@@ -150,5 +150,10 @@ def test_full_depth_cfg2_and_cfg3_batch_invariance_and_repeatability():
             assert together[b] == alone, b
             assert len(alone) == 12 and all(0 <= t < 32000 for t in alone)
         assert together[0] != together[1]                                       # different clips, different captions
+        # continuous batching at full size: 3 clips through 2 KV slots, EOS = a token that occurs in clip 1's caption
+        eos = together[1][4]
+        want = [t[: t.index(eos) + 1] if eos in t else t for t in together]
+        got = dict(eng.caption_stream(clips, 0.3, 12, eos_id=eos, slots=2, check_every=4))
+        assert [got[i] for i in range(3)] == want
     finally:
         eng.close()
