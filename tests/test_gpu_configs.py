@@ -157,3 +157,37 @@ def test_full_depth_cfg2_and_cfg3_batch_invariance_and_repeatability():
         assert [got[i] for i in range(3)] == want
     finally:
         eng.close()
+
+
+def test_vit_h_full_depth_every_layer_teacher_forced():
+    """The complete vision tower at its real size (ViT-H/14-378, all 31 evaluated layers, r = 15: 730 -> 265 tokens) for one
+    frame.  Run end to end, fp16 and fp32 arithmetic pick different merge pairs at some near tie within 31 steps and the
+    token sets drift apart (measured: 6.5 % on the mean feature), so every layer is checked on ITS OWN input
+    instead: indices bit-exact against the C oracle fed with the GPU's metric, layer output against the CPU oracle with
+    the same merge forced, then the GPU output becomes the next layer's input."""
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine
+    v = S.AURORACAP_7B["vit"]
+    wg = S.vit_weights(v)
+    f32 = lambda d: {k: ([f32(x) for x in val] if isinstance(val, list) else val.float().cpu()) for k, val in d.items()}
+    w = f32(wg)
+    eng = AuroraCapEngine({"vit": v, "llm": None}, {"vit": wg}, max_frames=1, max_batch=1, max_ctx=128, max_new_tokens=8)
+    try:
+        r = eng.tome_r(0.3)
+        assert r == 15
+        x = O.vit_embed(S.frames(1, 3).float().cpu(), w, 14, v.get("layer_norm_eps", 1e-5)).half().float()
+        size, worst = None, 0.0
+        for layer in range(v["num_hidden_layers"] - 1):
+            xo, so, metric, idx = eng.vit_layer(layer, x, size, r)
+            mc = tome_ref.match(metric.cpu().numpy(), r)
+            for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+                np.testing.assert_array_equal(idx[k].cpu().numpy(), mc[k], err_msg=f"layer {layer} {k}")
+            xr, _ = O.vit_layer(x, size, w["layers"][layer], v["num_attention_heads"], r, v["hidden_act"], forced_match=to_match(idx))
+            err = rel_l2(xo.float().cpu(), xr)
+            worst = max(worst, err)
+            assert err < 5e-3, (layer, err)
+            assert xo.shape[1] == x.shape[1] - r
+            x, size = xo.float().cpu(), so.cpu()[..., None]
+        assert x.shape[1] == 265                                                  # 264 patch tokens + CLS enter layer 31
+    finally:
+        eng.close()
