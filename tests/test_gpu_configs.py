@@ -191,3 +191,34 @@ def test_vit_h_full_depth_every_layer_teacher_forced():
         assert x.shape[1] == 265                                                  # 264 patch tokens + CLS enter layer 31
     finally:
         eng.close()
+
+
+def test_llama_7b_full_depth_teacher_forced_logits():
+    """Vicuna/Llama-7B at its real size (32 layers x d 4096 x MLP 11008, vocab 32000, linear RoPE scaling 4) with the seeded
+    synthetic weights: a 96-token prefix + 5 greedy tokens; the CPU oracle replays the GPU's own tokens in one fp32 pass
+    (teacher forcing) and its logits must match at every generated position within the tolerance of the small-model
+    tests - the norm-free decode step and the paged KV path are exercised at full depth."""
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.test_gpu_llm import LOGIT_TOL, padded, teacher_forced_logits
+    cfg = S.VICUNA_7B_16K
+    wg = S.llm_weights(cfg)
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": wg}, max_frames=1, max_batch=1, max_ctx=256, max_new_tokens=8)
+    try:
+        emb = (torch.randn(96, 4096, generator=torch.Generator().manual_seed(4)) * 0.02).half().float()
+        eng.begin_batch(1, 6, None)
+        eng.prefill(0, padded(emb), 96)
+        logits = [eng.logits()[0].cpu()]
+        for _ in range(5):
+            eng.decode(1)
+            logits.append(eng.logits()[0].cpu())
+        ids = eng.outputs()[0]
+    finally:
+        eng.close()
+    f32 = lambda d: {k: ([f32(x) for x in val] if isinstance(val, list) else val.float().cpu()) for k, val in d.items()}
+    w = f32(wg)
+    del wg
+    ref = teacher_forced_logits(emb, ids, w, cfg)
+    scale = ref.abs().max().item()
+    for i in range(6):
+        assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, (i, (logits[i] - ref[i]).abs().max().item(), scale)
