@@ -222,3 +222,30 @@ def test_llama_7b_full_depth_teacher_forced_logits():
     scale = ref.abs().max().item()
     for i in range(6):
         assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, (i, (logits[i] - ref[i]).abs().max().item(), scale)
+
+
+def test_projector_and_splice_at_real_size():
+    """Projector 1280 -> 4096 -> 4096 (erf GELU) + prefix splice for cfg2's 8 x 264 visual tokens and a 30-token prompt."""
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine
+    cfg = dict(LLAMA_7B_WIDTH, num_hidden_layers=1)
+    w = {"projector": {k: v.float().cpu() for k, v in S.projector_weights(1280, 4096).items()}, "llm": rand_llm_weights(cfg, 3, wstd=0.02)}
+    eng = AuroraCapEngine({"vit": VIT_H, "llm": cfg}, w, max_frames=8, max_batch=1, max_ctx=2304, max_new_tokens=8)   # vit: dims only
+    try:
+        vis = (torch.randn(8, 264, 1280, generator=torch.Generator().manual_seed(2)) * 0.5).half()
+        ids = S.prompt_ids(8, 0)
+        emb, L = eng.project_splice(vis, ids)
+        ref = O.splice(torch.tensor(ids), w["llm"]["embed_tokens.weight"],
+                       O.projector(vis.float().reshape(1, -1, 1280), w["projector"]).reshape(8, 264, -1))
+        assert L == ref.shape[0] == 30 + 8 * 264
+        assert rel_l2(emb[:L].float().cpu(), ref) < 5e-3
+        text_rows = [i for i, t in enumerate(ids) if t != -200]
+        row = 0
+        for t in ids:                                               # text rows are exact copies of the embedding table
+            if t == -200:
+                row += 264
+            else:
+                assert torch.equal(emb[row].cpu(), w["llm"]["embed_tokens.weight"][t].half())
+                row += 1
+    finally:
+        eng.close()
