@@ -39,12 +39,102 @@ __device__ __forceinline__ float ssq_to_rstd(unsigned long long s, int k, float 
     return rsqrtf((float)((double)s * (1.0 / 268435456.0)) / (float)k + eps);
 }
 
+// Epilogue shared by every skinny-GEMM structure: the lane holds acc[t][nb][i] = y[n = (tile0 + t) * 16 + 4g + i][b = nb * 16 + c]
+// (MFMA 16x16x32 C/D map), already reduced over K.  SK_QKV: a Q / K workgroup-unit is one PAIRED 32-column block (NT == 2:
+// tiles 2p and 2p + 1 hold d and its RoPE partner d + hd/2); a V unit is NT consecutive n16 tiles.
+template <int NT, int MODE, int NB>
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile0, f4 (&acc)[NT][NB], const int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = nb * 16 + c;
+        if (b < a.b_lo || b >= a.b_hi) continue;
+        if (a.ssq_in) {                                   // folded RMSNorm: per-row 1/rms of the (un-normalised) input
+            const float rstd = ssq_to_rstd(a.ssq_in[b], a.K, a.norm_eps);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][nb][i] *= rstd;
+        }
+        if (MODE == SK_ROW || MODE == SK_LOGITS || MODE == SK_SILU_MUL) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tile = tile0 + t;
+                const int n = tile * 16 + 4 * g;
+                if (n >= a.n_real) continue;
+                if (MODE == SK_LOGITS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a.out32[(int64_t)b * a.n_real + n + i] = acc[t][nb][i];
+                } else if (MODE == SK_SILU_MUL) {
+                    // h[b][k], k = n/2 + {0,1} = tile*8 + 2g + {0,1}, written in x-fragment form for the down projection
+                    h2 o;
+                    o[0] = (half_t)(silu_f(acc[t][nb][0]) * acc[t][nb][1]);
+                    o[1] = (half_t)(silu_f(acc[t][nb][2]) * acc[t][nb][3]);
+                    half_t* dst = a.out_f + ((((int64_t)(b >> 4) * a.out_k32 + (tile >> 2)) * 64) + (tile & 3) * 16 + (b & 15)) * 8 + 2 * g;
+                    *(h2*)dst = o;
+                } else {
+                    // residual update in place, in x-fragment form: x[b][n..n+3] += y; and sum(x_new^2) for the next norm
+                    half_t* px = a.xres + xfrag_piece(b, n & ~7, a.n_real >> 5) + (n & 7);
+                    const h4 rr = *(const h4*)px;
+                    h4 o;
+                    float p = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o[i] = (half_t)(acc[t][nb][i] + (float)rr[i]);
+                        p += (float)o[i] * (float)o[i];
+                    }
+                    *(h4*)px = o;
+                    p += __shfl_xor(p, 16, 64);
+                    p += __shfl_xor(p, 32, 64);
+                    if (g == 0 && a.ssq_out) atomicAdd(a.ssq_out + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
+                }
+            }
+        } else {                  // SK_QKV: one PAIRED 32-column block (Q / K, NT == 2) or NT n16 tiles of V
+            const KvLayout& kv = a.kv;
+            const int nbc = tile0 * 16;
+            const int pos = a.pos[b];
+            const int seq = a.seq_ids ? a.seq_ids[b] : b;
+            half_t* page = kv_page(kv, seq, pos);
+            if (nbc < a.q_cols + a.k_cols) {
+                const bool is_q = nbc < a.q_cols;
+                const int nreg = is_q ? nbc : nbc - a.q_cols;
+                const int blkg = nreg >> 5;
+                const int head = blkg / kv.kblk, blk = blkg % kv.kblk;
+                if (head >= kv.heads) continue;
+                const float2* cs = a.rope + (int64_t)pos * (a.hd >> 1) + blk * 16 + 4 * g;
+                h8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 cc = cs[i];
+                    const float x1 = acc[0][nb][i], x2 = acc[NT - 1][nb][i];
+                    o[i] = (half_t)(x1 * cc.x - x2 * cc.y);
+                    o[4 + i] = (half_t)(x2 * cc.x + x1 * cc.y);
+                }
+                if (is_q) *(h8*)(a.qbuf + ((((int64_t)b * kv.heads + head) * kv.kblk + blk) * 4 + g) * 8) = o;
+                else *(h8*)(page + kfrag_off(kv, head, (pos % kv.page_tokens) >> 4, blk) + (g * 16 + (pos & 15)) * 8) = o;
+            } else {
+                const int nreg = nbc - a.q_cols - a.k_cols;
+                const int tp = pos & 31;
+                const int gt = (tp & 15) >> 2, jt = (tp & 3) + ((tp >> 4) << 2);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int idx = (nreg >> 4) + t;
+                    const int head = idx / kv.vd16, d16 = idx % kv.vd16;
+                    if (head >= kv.heads) continue;
+                    half_t* fr = page + vfrag_off(kv, head, d16, (pos % kv.page_tokens) >> 5);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fr[(gt * 16 + 4 * g + i) * 8 + jt] = (half_t)acc[t][nb][i];
+                }
+            }
+        }
+    }
+}
+
 template <int NT, int MODE, int NW, int NB>
 __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g = lane >> 4;
     if (a.ssq_zero && blockIdx.x == 0 && tid < AUR_MAX_BATCH) a.ssq_zero[tid] = 0ull;     // reset the accumulator a LATER kernel fills
     const int K32 = a.K >> 5;
     const int tile0 = blockIdx.x * NT;
@@ -180,89 +270,276 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
             acc[t][nb] = s;
         }
 
+    skinny_store<NT, MODE, NB>(a, tile0, acc, lane);
+}
+
+// ------------------------------------------------------------------------------------ skinny GEMM, x through LDS
+// Structure for engines that decode MORE than 32 sequences at once (3-4 MFMA column groups).  There the x fragments a wave needs
+// outweigh its weight fragments (4 KiB of x per KiB of W for a one-tile wave), and every byte of it crosses the same per-CU vector
+// memory path as the HBM stream: measured at B = 64 on MI355X the per-wave-x kernel above spends 40-50 % of its time on x
+// (gate/up 49 us vs 32 us with the x loads stubbed out; tools/gemv_lab).  Here ONE workgroup per CU owns T consecutive n16 tiles
+// (T x KS consumer waves: wave -> tile w / KS, k phase w % KS) and NL LOADER waves bring the x fragments in once per workgroup by
+// LDS-DMA (global_load_lds, x-fragment form is already lane-linear), chunk by chunk (KC k32 tiles x NB column groups) into a ring
+// of NBUF LDS buffers behind a COUNTED vmcnt; one s_barrier per chunk hands chunk ci to the consumers and chunk ci-1's buffer back
+// to the loaders.  Consumers stream their weight fragments straight into VGPRs (U-deep register pipeline that runs across chunk
+// boundaries; their vmcnt never sees a DMA) and read x with conflict-free ds_read_b128.  x traffic per CU drops from
+// (tiles per CU) x |x| to |x|; barriers are rare (KC = 8: 16 per K = 4096).
+//
+// Accumulation order per output is fixed by (KS, KC, S) - shape constants - never by the batch: bitwise deterministic and
+// batch-invariant like the kernel above.
+//
+// SK_ROW (N = hidden: one tile per CU) cannot share x across tiles without splitting K across workgroups: blockIdx.y = k split s
+// of S, each workgroup writes its fp32 partial tile lane-linearly, and skinny_row_reduce_kernel sums the S partials in fixed order
+// and applies the residual / sum(x^2) epilogue.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define SKX_BAR()                              \
+    do {                                       \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+        asm volatile("" ::: "memory");         \
+    } while (0)
+
+// tiles of workgroup c: SK_QKV: unit c = PAIRED block c (tiles 2c, 2c + 1) + V tile v0 + c; otherwise tiles_lo (+1 for c < n_hi) consecutive
+struct SkxGeom {
+    int tiles_lo, n_hi;     // generic split of N16 tiles over gridDim.x workgroups
+    int v_tile0;            // SK_QKV: first V tile (= (q_cols + k_cols) / 16)
+    int S;                  // k splits (gridDim.y); > 1 only for SK_ROW
+    float* part;            // SK_ROW split-K partials, lane-linear [S][N16][NB][64][4]
+};
+
+template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
+__global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(SkinnyArgs a, SkxGeom gm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB
+    constexpr int NCW = T_MAX * KS, Q = KC / KS;                        // consumer waves; steps per wave per chunk
+    constexpr int PIECES = KC * NB / NL;                                // DMA instructions per chunk per loader wave
+    constexpr int CHUNK_BYTES = KC * NB * 1024;
+    static_assert(KC % KS == 0 && (Q % U == 0 || U % Q == 0), "chunk steps per wave vs pipeline depth");
+    static_assert((KC * NB) % NL == 0, "pieces per chunk must split evenly over the loader waves");
+    static_assert((NBUF - 1) * PIECES <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
+    static_assert(MODE != SK_QKV || T_MAX == 3, "SK_QKV: a workgroup owns one PAIRED block + one V tile");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x, s = blockIdx.y;
+    if (a.ssq_zero && c == 0 && s == 0 && tid < AUR_MAX_BATCH) a.ssq_zero[tid] = 0ull;    // reset the accumulator a LATER kernel fills
+    const int K32 = a.K >> 5, KE = K32 / gm.S, kb = s * KE;
+    const int nchunk = (KE + KC - 1) / KC;
+
+    if (w >= NCW) {                                            // ---------------- loader waves (piece q of a chunk -> loader q % NL)
+        const int lw = w - NCW;
+        auto issue = [&](int ci) {
+            char* buf = smem + (ci % NBUF) * CHUNK_BYTES;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int b = nb * 16 + c;
-        if (b < a.b_lo || b >= a.b_hi) continue;
-        if (a.ssq_in) {                                   // folded RMSNorm: per-row 1/rms of the (un-normalised) input
-            const float rstd = ssq_to_rstd(a.ssq_in[b], a.K, a.norm_eps);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][nb][i] *= rstd;
+            for (int q = 0; q < PIECES; ++q) {
+                const int piece = q * NL + lw, kk = piece / NB, nb = piece % NB;
+                int kr = ci * KC + kk;
+                kr = kr < KE ? kr : KE - 1;                    // always PIECES instructions per chunk: the vmcnt below counts them
+                glds16(a.xf + ((int64_t)nb * K32 + kb + kr) * AUR_FRAG_HALVES + lane * 8, buf + piece * 1024);
+            }
+        };
+        int next = 0;
+        for (; next < NBUF - 1 && next < nchunk; ++next) issue(next);
+        for (int ci = 0; ci < nchunk; ++ci) {
+            switch (next - ci - 1) {                           // chunks that may stay in flight once chunk ci has landed (<= NBUF - 2)
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<PIECES>(); break;
+                case 2: wait_vmcnt<(NBUF > 3 ? 2 : 0) * PIECES>(); break;
+                case 3: wait_vmcnt<(NBUF > 4 ? 3 : 0) * PIECES>(); break;
+                case 4: wait_vmcnt<(NBUF > 5 ? 4 : 0) * PIECES>(); break;
+                case 5: wait_vmcnt<(NBUF > 6 ? 5 : 0) * PIECES>(); break;
+                case 6: wait_vmcnt<(NBUF > 7 ? 6 : 0) * PIECES>(); break;
+                default: wait_vmcnt<0>(); break;
+            }
+            SKX_BAR();                                         // chunk ci is in LDS; chunk ci-1's buffer is free again
+            if (next < nchunk) {
+                issue(next);
+                ++next;
+            }
         }
-        if (MODE == SK_ROW || MODE == SK_LOGITS || MODE == SK_SILU_MUL) {
+        return;
+    }
+    const int t = w / KS, p = w % KS;
+    int ntile, tile;
+    if (MODE == SK_QKV) {
+        ntile = 3;
+        tile = t < 2 ? 2 * c + t : gm.v_tile0 + c;
+    } else {
+        ntile = gm.tiles_lo + (c < gm.n_hi ? 1 : 0);
+        tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + t;
+    }
+    if (t >= ntile) return;                                    // idle consumer (ended waves do not count at s_barrier)
+    f4 acc[NB];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tile = tile0 + t;
-                const int n = tile * 16 + 4 * g;
-                if (n >= a.n_real) continue;
-                if (MODE == SK_LOGITS) {
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    const half_t* wbase = a.W + ((int64_t)tile * K32 + kb) * AUR_FRAG_HALVES + lane * 8;
+    const int NS = nchunk * Q;                                 // steps of this wave (the last chunk may hold invalid steps)
+    // step j -> chunk j / Q, kk = (j % Q) * KS + p; k index clamped: an invalid step re-reads the last fragment against x = 0
+    auto kof = [&](int j, bool& valid) {
+        const int kr = (j / Q) * KC + (j % Q) * KS + p;
+        valid = j < NS && kr < KE;
+        return valid ? kr : KE - 1;
+    };
+    h8 cw[U], nw[U];
+    bool vv;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a.out32[(int64_t)b * a.n_real + n + i] = acc[t][nb][i];
-                } else if (MODE == SK_SILU_MUL) {
-                    // h[b][k], k = n/2 + {0,1} = tile*8 + 2g + {0,1}, written in x-fragment form for the down projection
-                    h2 o;
-                    o[0] = (half_t)(silu_f(acc[t][nb][0]) * acc[t][nb][1]);
-                    o[1] = (half_t)(silu_f(acc[t][nb][2]) * acc[t][nb][3]);
-                    half_t* dst = a.out_f + ((((int64_t)(b >> 4) * a.out_k32 + (tile >> 2)) * 64) + (tile & 3) * 16 + (b & 15)) * 8 + 2 * g;
-                    *(h2*)dst = o;
-                } else {
-                    // residual update in place, in x-fragment form: x[b][n..n+3] += y; and sum(x_new^2) for the next norm
-                    half_t* px = a.xres + xfrag_piece(b, n & ~7, a.n_real >> 5) + (n & 7);
-                    const h4 rr = *(const h4*)px;
-                    h4 o;
-                    float p = 0.f;
+    for (int u = 0; u < U; ++u) cw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(u, vv) * AUR_FRAG_HALVES));
+    for (int j0 = 0; j0 < NS; j0 += U) {
+        const bool more = j0 + U < NS;
+        if (more) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o[i] = (half_t)(acc[t][nb][i] + (float)rr[i]);
-                        p += (float)o[i] * (float)o[i];
-                    }
-                    *(h4*)px = o;
-                    p += __shfl_xor(p, 16, 64);
-                    p += __shfl_xor(p, 32, 64);
-                    if (g == 0 && a.ssq_out) atomicAdd(a.ssq_out + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
-                }
+            for (int u = 0; u < U; ++u) nw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(j0 + U + u, vv) * AUR_FRAG_HALVES));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            if (j < NS && j % Q == 0) SKX_BAR();               // chunk j / Q landed (and chunk j / Q - 1 is released)
+            const int ci = j / Q, kk = (j % Q) * KS + p;
+            const char* buf = smem + (ci % NBUF) * CHUNK_BYTES + lane * 16;
+            bool valid;
+            (void)kof(j, valid);
+            h8 xr[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) xr[nb] = *(const h8*)(buf + (kk * NB + nb) * 1024);
+            if (!valid) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) xr[nb] = h8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-        } else if (NT == 2) {     // SK_QKV: the workgroup owns one PAIRED 32-column block
-            const KvLayout& kv = a.kv;
-            const int nbc = tile0 * 16;
-            const int pos = a.pos[b];
-            const int seq = a.seq_ids ? a.seq_ids[b] : b;
-            half_t* page = kv_page(kv, seq, pos);
-            if (nbc < a.q_cols + a.k_cols) {
-                const bool is_q = nbc < a.q_cols;
-                const int nreg = is_q ? nbc : nbc - a.q_cols;
-                const int blkg = nreg >> 5;
-                const int head = blkg / kv.kblk, blk = blkg % kv.kblk;
-                if (head >= kv.heads) continue;
-                const float2* cs = a.rope + (int64_t)pos * (a.hd >> 1) + blk * 16 + 4 * g;
-                h8 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float2 cc = cs[i];
-                    const float x1 = acc[0][nb][i], x2 = acc[NT - 1][nb][i];
-                    o[i] = (half_t)(x1 * cc.x - x2 * cc.y);
-                    o[4 + i] = (half_t)(x2 * cc.x + x1 * cc.y);
-                }
-                if (is_q) *(h8*)(a.qbuf + ((((int64_t)b * kv.heads + head) * kv.kblk + blk) * 4 + g) * 8) = o;
-                else *(h8*)(page + kfrag_off(kv, head, (pos % kv.page_tokens) >> 4, blk) + (g * 16 + (pos & 15)) * 8) = o;
-            } else {
-                const int nreg = nbc - a.q_cols - a.k_cols;
-                const int tp = pos & 31;
-                const int gt = (tp & 15) >> 2, jt = (tp & 3) + ((tp >> 4) << 2);
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(cw[u], xr[nb], acc[nb]);
+        }
+        if (more) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int idx = (nreg >> 4) + t;
-                    const int head = idx / kv.vd16, d16 = idx % kv.vd16;
-                    if (head >= kv.heads) continue;
-                    half_t* fr = page + vfrag_off(kv, head, d16, (pos % kv.page_tokens) >> 5);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fr[(gt * 16 + 4 * g + i) * 8 + jt] = (half_t)acc[t][nb][i];
-                }
-            }
+            for (int u = 0; u < U; ++u) cw[u] = nw[u];
         }
     }
+    // ---- K phases of a tile (and, for SK_QKV, the two tiles of a PAIRED block) meet in LDS; fixed summation order
+    if (KS > 1 || MODE == SK_QKV) {
+        SKX_BAR();                                             // every consumer is done reading x (the loaders have exited)
+        float* red = (float*)smem;                             // [consumer wave][NB][64][4]  (<= 12 x 4 KiB: inside the ring)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
+        SKX_BAR();
+        if (p != 0) return;
+        if (MODE == SK_QKV && t == 1) return;                  // its tile is stored by the owner of the PAIRED block (t == 0)
+        auto gather = [&](int w0, f4 (&dst)[NB]) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f4 sum = *(const f4*)(red + ((w0 * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                for (int pp = 1; pp < KS; ++pp) {
+                    const f4 q = *(const f4*)(red + (((w0 + pp) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum[i] += q[i];
+                }
+                dst[nb] = sum;
+            }
+        };
+        if (MODE == SK_QKV && t == 0) {
+            f4 pr[2][NB];
+            gather(0, pr[0]);
+            gather(KS, pr[1]);
+            skinny_store<2, MODE, NB>(a, tile, pr, lane);
+            return;
+        }
+        gather(w, acc);
+    }
+    if (MODE == SK_ROW && gm.S > 1) {                          // split-K partial, lane-linear: one 16-byte store per lane and column group
+        const int N16 = a.Npad >> 4;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
+        return;
+    }
+    f4 one[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) one[0][nb] = acc[nb];
+    skinny_store<1, MODE, NB>(a, tile, one, lane);
+}
+
+// second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, SkxGeom gm) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N16 = a.Npad >> 4;
+    if (tile >= N16) return;
+    f4 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[0][nb] = *(const f4*)(gm.part + (((int64_t)tile * NB + nb) * 64 + lane) * 4);
+    for (int s = 1; s < gm.S; ++s) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f4 q = *(const f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][nb][i] += q[i];
+        }
+    }
+    skinny_store<1, SK_ROW, NB>(a, tile, acc, lane);
+}
+
+static int g_skx_cus = 256;
+
+template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
+static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid, hipStream_t s) {
+    constexpr int lds = NBUF * KC * NB * 1024;
+    static_assert(lds >= T_MAX * KS * NB * 1024, "the reduction scratch lives inside the x ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL>), grid, dim3(64 * (T_MAX * KS + NL)), lds, s, a, gm);
+    return hipGetLastError();
+}
+
+template <int NB>
+static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s) {
+    const int N16 = a.Npad >> 4, K32 = a.K >> 5;
+    SkxGeom gm{};
+    gm.S = 1;
+    gm.part = part;
+    auto split = [&](int tmax) {                               // N16 tiles over min(N16, max(#CUs, ceil(N16 / tmax))) workgroups
+        int G = (N16 + tmax - 1) / tmax;
+        if (G < g_skx_cus) G = N16 < g_skx_cus ? N16 : g_skx_cus;
+        gm.tiles_lo = N16 / G;
+        gm.n_hi = N16 % G;
+        return G;
+    };
+    switch (a.mode) {
+        case SK_QKV: {
+            // workgroup c: PAIRED block c of the Q / K region + V tile c (equal counts by construction: q_cols == k_cols == V cols)
+            const int pairs = (a.q_cols + a.k_cols) >> 5;
+            gm.v_tile0 = (a.q_cols + a.k_cols) >> 4;
+            if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
+            return launch_skx_t<3, 4, SK_QKV, NB, 8, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
+        }
+        case SK_SILU_MUL: return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
+        case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, 8, 4, 4, 4>(a, gm, dim3(split(8), 1), s);
+        case SK_ROW: {
+            // split-K 4: 4 tiles x 3 k phases per workgroup, N16 / 4 n-blocks x 4 k splits (= 256 workgroups at N = 4096)
+            gm.S = 4;
+            gm.tiles_lo = 4;
+            gm.n_hi = 0;
+            hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, 6, 5, 2, 2>(a, gm, dim3(N16 / 4, 4), s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((skinny_row_reduce_kernel<NB>), dim3((N16 + 3) / 4), dim3(256), 0, s, a, gm);
+            return hipGetLastError();
+        }
+    }
+    (void)K32;
+    return hipErrorInvalidValue;
+}
+
+// SK_ROW takes the split-K LDS structure only where it pays (K >= 8192: the down projection; at K = 4096 the extra kernel
+// boundary of the reduce eats the gain: o projection 13.7 us either way, tools/gemv_lab)
+bool skinny_lds_applies(const SkinnyArgs& a) {
+    if (a.variant != 1) return false;
+    if (a.mode == SK_ROW) return a.part != nullptr && (a.K & 127) == 0 && (a.Npad & 63) == 0;      // the engine passes part for K >= 8192
+    return true;
 }
 
 template <int NT, int MODE, int NW, int NB>
@@ -272,7 +549,12 @@ static hipError_t launch_skinny_t(const SkinnyArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t skinny_init() { return hipSuccess; }      // <= 32 KiB of LDS: no attribute needed
+hipError_t skinny_init() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        g_skx_cus = cus;
+    return hipSuccess;
+}
 
 template <int NB>
 static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
@@ -290,6 +572,14 @@ static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > AUR_MAX_BATCH || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
+    if (skinny_lds_applies(a)) {
+        switch ((a.B + 15) >> 4) {
+            case 1: return launch_skx_nb<1>(a, a.part, s);
+            case 2: return launch_skx_nb<2>(a, a.part, s);
+            case 3: return launch_skx_nb<3>(a, a.part, s);
+            default: return launch_skx_nb<4>(a, a.part, s);
+        }
+    }
     switch ((a.B + 15) >> 4) {                              // MFMA column groups of 16 batch rows
         case 1: return launch_skinny_nb<1>(a, s);
         case 2: return launch_skinny_nb<2>(a, s);

@@ -69,6 +69,8 @@ struct aur_ctx {
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
+    int skinny_variant = 0, row_split_min_k = 8192;                             // decode projections: x through LDS (engines of > 32 slots)
+    float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
@@ -176,6 +178,7 @@ static void derive(aur_ctx* c) {
     c->l_ctx_pad = c->l_max_pages * g.page_tokens;
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
     c->nbanks = g.num_banks == 2 ? 2 : 1;
+    c->skinny_variant = g.max_batch > 32 ? 1 : 0;        // a function of the engine's capacity, never of the live batch
     c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch * c->nbanks;
     // decode attention: one wave per (sequence, head, split).  Enough splits to put ~512 waves on the GPU for small batches,
     // as few as possible (2) once the batch supplies them - every extra split re-reads q, writes a partial and lengthens
@@ -238,6 +241,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_attn = k.take<half_t>(Bp * d);                    // attention output  (x-fragment form)
     c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
+    c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * B * c->l_max_pages);
@@ -712,7 +716,7 @@ extern "C" int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t
     CK(launch_xfrag_pack((const half_t*)a, k, m, k, ctx->d_scr, st));
     SkinnyArgs s{};
     s.xf = ctx->d_scr; s.W = (const half_t*)w_packed; s.B = m; s.b_lo = 0; s.b_hi = m; s.Npad = npad; s.K = k; s.n_real = n;
-    s.mode = SK_LOGITS; s.out32 = out;
+    s.mode = SK_LOGITS; s.out32 = out; s.variant = ctx->skinny_variant;
     CK(launch_skinny(s, st));
     return AUR_OK;
 }
@@ -799,6 +803,7 @@ static int lm_head_and_advance(aur_ctx* ctx, int b0, int nb, int advance, int se
     SkinnyArgs h{};
     h.xf = ctx->d_x; h.W = ctx->l_head_w; h.B = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = g.llm_hidden; h.n_real = g.llm_vocab;
     h.mode = SK_LOGITS; h.out32 = ctx->d_logits; h.b_lo = b0; h.b_hi = b0 + nb; h.ssq_in = ctx->s_ssq_mlp; h.norm_eps = g.llm_rms_eps;
+    h.variant = ctx->skinny_variant;
     CK(launch_skinny(h, s));
     CK(launch_argmax_advance(ctx->d_logits, b0, nb, g.llm_vocab, ctx->l_embed, g.llm_hidden, ctx->eos, ctx->max_new, ctx->s_ids, ctx->s_len,
                              ctx->s_fin, ctx->s_pos, ctx->d_x, ctx->s_ssq_mlp, advance, set_pos, s));
@@ -881,7 +886,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant;
     return q;
 }
 static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
@@ -897,6 +902,7 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     SkinnyArgs o{};
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
     o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
+    o.variant = ctx->skinny_variant; o.part = d >= ctx->row_split_min_k ? ctx->d_part_row : nullptr;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -905,7 +911,7 @@ static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     SkinnyArgs gu{};
     gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
     gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
-    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant;
     return gu;
 }
 static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
@@ -914,6 +920,7 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     SkinnyArgs dn{};
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
     dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
+    dn.variant = ctx->skinny_variant; dn.part = g.llm_mlp >= ctx->row_split_min_k ? ctx->d_part_row : nullptr;
     return dn;
 }
 
@@ -1030,6 +1037,8 @@ extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
 extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
+    else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
+    else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
     else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);
 
@@ -1069,7 +1078,7 @@ extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, d
             SkinnyArgs h{};
             h.ssq_in = ctx->s_ssq_mlp; h.norm_eps = g.llm_rms_eps;
             h.xf = ctx->d_x; h.W = ctx->l_head_w; h.B = ctx->batch; h.b_lo = 0; h.b_hi = ctx->batch; h.Npad = ctx->l_vocab_pad; h.K = d;
-            h.n_real = g.llm_vocab; h.mode = SK_LOGITS; h.out32 = ctx->d_logits;
+            h.n_real = g.llm_vocab; h.mode = SK_LOGITS; h.out32 = ctx->d_logits; h.variant = ctx->skinny_variant;
             CK(launch_skinny(h, s));
         } else {
             int bit = !strcmp(kernel, "pre_norm") ? 1 : !strcmp(kernel, "pre_qkv") ? 2 : !strcmp(kernel, "pre_attn") ? 4 : !strcmp(kernel, "pre_o") ? 8

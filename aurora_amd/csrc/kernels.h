@@ -128,6 +128,10 @@ struct SkinnyArgs {
     const float2* rope;
     const int32_t* pos;     // [B] device: position of the new token (= tokens already cached)
     const int32_t* seq_ids; // [B] page-table rows (nullptr = identity)
+    // structure: 0 = x fragments per wave from L2 (engines of <= 32 decode slots), 1 = x through LDS once per workgroup
+    // (decode.hip "skinny GEMM, x through LDS").  Chosen per ENGINE (capacity), never per live batch: batch invariance.
+    int variant;
+    float* part;            // variant 1, SK_ROW: split-K partials [4][Npad/16][ceil(B/16)][64][4] fp32 (nullptr: keep structure 0)
 };
 enum { SK_ROW = 0, SK_LOGITS = 1, SK_SILU_MUL = 2, SK_QKV = 3 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);

@@ -43,7 +43,7 @@ class AuroraCapEngine:
             raise _lib.AuroraHipError("AuroraCapEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback")
         self.L = _lib.lib()
-        self.dev = torch.device(device)
+        self.dev = self.normalize_device(device)
         torch.cuda.set_device(self.dev)
         # All work is enqueued on ONE explicit (non-null) HIP stream: the null stream cannot be captured into
         # a hipGraph.  It becomes this thread's current torch stream, so caller-side tensor housekeeping is
@@ -106,6 +106,17 @@ class AuroraCapEngine:
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ housekeeping
+    @staticmethod
+    def normalize_device(device) -> torch.device:
+        """"cuda" (no ordinal, the lmms-eval adaptor's default) -> the process's current GPU: torch.cuda.set_device and the
+        allocations below need an indexed device."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.AuroraHipError(f"AuroraCapEngine runs on a ROCm GPU only (device={device!r}); there is no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
+
     def close(self):
         if getattr(self, "ctx", None):
             torch.cuda.synchronize()
@@ -426,7 +437,7 @@ class AuroraCapEngine:
         rs, plans = [], []
         for px, ids in clips:
             r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
-            t0 = (self.v["image_size"] // self.v["patch_size"]) ** 2 + 1
+            t0 = (px.shape[-2] // self.v["patch_size"]) * (px.shape[-1] // self.v["patch_size"]) + 1     # as vit_encode counts them
             rs.append(r)
             plans.append(self.splice_plan(ids, px.shape[0], tokens_at_layer(t0, r, self.v["num_hidden_layers"] - 1) - 1))
         self.begin_batch(B, max_new_tokens, eos_id)
@@ -466,11 +477,14 @@ class AuroraCapEngine:
         return lens, fin
 
     def caption_stream(self, clips, token_kept_ratio: float, max_new_tokens: int, eos_id: Optional[int] = 2, slots: Optional[int] = None,
-                       check_every: int = 16):
+                       check_every: int = 16, on_error=None):
         """Continuous batching over an iterable of (pixel_values, input_ids): up to `slots` (default max_batch) captions are
         in flight; every `check_every` decode steps the finished slots are collected and re-filled with the next clips
         (ViT + projector + prefill into the free slot while the others keep their KV and state).  Yields (index, ids) in
-        completion order; each clip's ids equal what it produces alone (batch-invariant kernels)."""
+        completion order; each clip's ids equal what it produces alone (batch-invariant kernels).
+        on_error(index, exception): a clip whose front end is rejected (shape, context longer than max_ctx, ...) is reported
+        and skipped while the captions in flight keep going (the reference harness turns a failing request into an empty
+        caption, lmms_eval/models/auroracap.py:511-514); None = raise."""
         B = self.max_batch if slots is None else slots
         if not 1 <= B <= self.max_batch:
             raise ValueError(f"slots={B} for an engine built with max_batch={self.max_batch}")
@@ -482,19 +496,23 @@ class AuroraCapEngine:
         exhausted = False
         while True:
             for s in range(B):                                    # fill every free slot
-                if owner[s] is not None or exhausted:
-                    continue
-                nxt = next(it, None)
-                if nxt is None:
-                    exhausted = True
-                    break
-                idx, (px, ids) = nxt
-                r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
-                vis = self.vit_encode(px, r)
-                emb, L = self.project_splice(vis, list(ids))
-                self.slot_reset(s)
-                self.prefill(s, emb, L)
-                owner[s] = idx
+                while owner[s] is None and not exhausted:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        exhausted = True
+                        break
+                    idx, (px, ids) = nxt
+                    try:
+                        r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
+                        vis = self.vit_encode(px, r)
+                        emb, L = self.project_splice(vis, list(ids))
+                        self.slot_reset(s)
+                        self.prefill(s, emb, L)                   # argument checks come before any enqueue: a rejection leaves the slot idle
+                        owner[s] = idx
+                    except (ValueError, IndexError, AssertionError, _lib.AuroraHipError) as e:
+                        if on_error is None:
+                            raise
+                        on_error(idx, e)
             if all(o is None for o in owner):
                 return
             self.decode(check_every)

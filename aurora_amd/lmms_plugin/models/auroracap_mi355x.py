@@ -118,10 +118,17 @@ class AuroraCapMI355X(_Base):
         super().__init__()
         assert kwargs == {}, f"Unexpected kwargs: {kwargs}"                 # auroracap.py:67
         self.slowfast = bool(slowfast)                                       # first frame unmerged (aurora.py:223-246)
-        self._rank = int(os.environ.get("RANK", 0))                           # one process per GPU (accelerate / torchrun)
-        self._world_size = int(os.environ.get("WORLD_SIZE", 1))
-        local = int(os.environ.get("LOCAL_RANK", 0))
-        self._device = torch.device(f"cuda:{local}") if self._world_size > 1 else torch.device(device)
+        # one process per GPU (accelerate launch / torchrun).  The harness calls lm.accelerator.gather / wait_for_everyone
+        # whenever lm.world_size > 1 (evaluator.py:426-428, 457): DistShim provides exactly those over RCCL.
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            from ...parallel import DistShim
+            self.accelerator = DistShim()
+            self._rank, self._world_size = self.accelerator.process_index, self.accelerator.num_processes
+            self._device = torch.device("cuda", self.accelerator.local_process_index) if self.accelerator.backend == "nccl" \
+                else torch.device(device)
+        else:
+            self._rank, self._world_size = 0, 1
+            self._device = torch.device(device)
         self.batch_size_per_gpu = int(batch_size)
         self.conv_template = conv_template
         self.token_merge_ratio = float(token_merge_ratio)
@@ -138,8 +145,13 @@ class AuroraCapMI355X(_Base):
             if not osp.isdir(pretrained):
                 from huggingface_hub import snapshot_download
                 pretrained = snapshot_download(repo_id=pretrained)
-            per_frame = (self.resolution // 14) ** 2                            # CLIP ViT-H/14, 32 layers (aurora.py:895)
-            n_kept_max = per_frame - 31 * max(int(per_frame * (1 - self.token_merge_ratio) / 32), 0)
+            from ...checkpoint import vit_config
+            from ...engine import tokens_at_layer, tome_r
+            vc = vit_config(osp.join(pretrained, "visual_encoder"))              # patch size / depth from config.json
+            per_frame = (self.resolution // vc["patch_size"]) ** 2
+            r = tome_r(self.resolution, self.resolution, vc["patch_size"], self.token_merge_ratio, vc["num_hidden_layers"])
+            n_kept_max = tokens_at_layer(per_frame + 1, r, vc["num_hidden_layers"] - 1) - 1
+            self._engine_max_new = int(max_new_tokens)
             self._model = AuroraModel.from_pretrained(
                 pretrained, max_frames=self.max_frames_num + 1, max_batch=min(self.batch_size_per_gpu, 64),
                 max_ctx=256 + (self.max_frames_num + 1) * n_kept_max + (per_frame if self.slowfast else 0) + max_new_tokens,
@@ -240,6 +252,8 @@ class AuroraCapMI355X(_Base):
         return pixel_values, tokenizer_image_token(prompt, self._tokenizer, IMAGE_TOKEN_INDEX)
 
     def generate_until(self, requests) -> List[str]:
+        import logging
+        log = logging.getLogger("lmms-eval")
         args_list = [r.args for r in requests]
         res: List[Optional[str]] = [None] * len(args_list)
 
@@ -248,24 +262,65 @@ class AuroraCapMI355X(_Base):
             if self.cache_hook is not None:
                 self.cache_hook.add_partial("generate_until", (args_list[i][0], gen), [res[i]])
 
+        def fail(i, gen, exc):
+            """auroracap.py:511-514: a failing request is logged and answered with "" - the evaluation goes on."""
+            log.error(f"Error {exc!r} in generating (request {i})")
+            res[i] = ""
+            if self.cache_hook is not None:
+                self.cache_hook.add_partial("generate_until", (args_list[i][0], gen), [""])
+
+        def clip_or_fail(i, gen):
+            try:
+                return self._clip(args_list[i])
+            except Exception as e:                                            # noqa: BLE001 - undecodable video, no frames, ...
+                fail(i, gen, e)
+                return None
+
+        cap = getattr(self, "_engine_max_new", None) or getattr(getattr(self._model, "engine", None), "max_new_tokens", None)
         stream = hasattr(self._model, "caption_stream") and not self.slowfast
         # with continuous batching a whole generation-kwargs group is one stream (clips are decoded / preprocessed lazily,
         # finished KV slots are re-filled); otherwise the group is cut into chunks of batch_size like the reference does
         for batch in plan_batches(args_list, lambda s: len(self.tok_encode(s)), len(args_list) if stream else self.batch_size):
             gen = gen_defaults(args_list[batch[0]][1])
+            if cap is not None and gen["max_new_tokens"] > cap:
+                log.warning(f"gen_kwargs max_new_tokens={gen['max_new_tokens']} exceeds the engine capacity {cap} "
+                            f"(constructor argument max_new_tokens): captions are cut at {cap} tokens")
             self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)
             if stream:
-                for k, ids in self._model.caption_stream((self._clip(args_list[i]) for i in batch), max_new_tokens=gen["max_new_tokens"]):
-                    deliver(batch[k], ids, gen)
+                order: List[int] = []                                         # stream position -> request index
+
+                def clips():
+                    for i in batch:
+                        c = clip_or_fail(i, gen)
+                        if c is not None:
+                            order.append(i)
+                            yield c
+                for k, ids in self._model.caption_stream(clips(), max_new_tokens=gen["max_new_tokens"],
+                                                         on_error=lambda k, e: fail(order[k], gen, e)):
+                    deliver(order[k], ids, gen)
             elif self.slowfast:                 # ragged per-frame token counts: one clip at a time through the three calls
                 for i in batch:
-                    px, tok_ids = self._clip(args_list[i])
-                    self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)     # the slow-fast forward leaves it at 1.0
-                    out = self._model({"pixel_values": px.unsqueeze(0), "input_ids": torch.tensor([tok_ids])}, mode="inference")
-                    deliver(i, self._model.llm.generate(**out, do_sample=False, num_beams=1,
-                                                        max_new_tokens=gen["max_new_tokens"])[0].tolist(), gen)
+                    c = clip_or_fail(i, gen)
+                    if c is None:
+                        continue
+                    px, tok_ids = c
+                    try:
+                        self._model.visual_encoder.reset_tome_r(self.token_merge_ratio)     # the slow-fast forward leaves it at 1.0
+                        out = self._model({"pixel_values": px.unsqueeze(0), "input_ids": torch.tensor([tok_ids])}, mode="inference")
+                        deliver(i, self._model.llm.generate(**out, do_sample=False, num_beams=1,
+                                                            max_new_tokens=gen["max_new_tokens"])[0].tolist(), gen)
+                    except Exception as e:                                    # noqa: BLE001
+                        fail(i, gen, e)
             else:
-                ids = self._model.caption_batch([self._clip(args_list[i]) for i in batch], max_new_tokens=gen["max_new_tokens"])
-                for i, x in zip(batch, ids):
-                    deliver(i, x, gen)
+                live = [(i, c) for i in batch for c in [clip_or_fail(i, gen)] if c is not None]
+                try:
+                    ids = self._model.caption_batch([c for _, c in live], max_new_tokens=gen["max_new_tokens"])
+                    for (i, _), x in zip(live, ids):
+                        deliver(i, x, gen)
+                except Exception:                                             # noqa: BLE001 - isolate the failing request
+                    for i, c in live:
+                        try:
+                            deliver(i, self._model.caption_batch([c], max_new_tokens=gen["max_new_tokens"])[0], gen)
+                        except Exception as e:                                # noqa: BLE001
+                            fail(i, gen, e)
         return res

@@ -53,3 +53,47 @@ def merge_round_robin(per_rank: dict, n_clips: int) -> List[Optional[List[int]]]
             if idx < n_clips:
                 out[idx] = ids
     return out
+
+
+class DistShim:
+    """The two calls the lmms-eval harness makes on `lm.accelerator` when `lm.world_size > 1`
+    (src/lmms-eval/lmms_eval/evaluator.py:426-428 `gather` of the per-rank instance count, :457 and :610-611
+    `wait_for_everyone`), over torch.distributed - RCCL on the GPU ranks, gloo on CPU in tests.  The reference adaptor gets
+    them from accelerate.Accelerator (lmms_eval/models/auroracap.py:70-134); this path has no model to `prepare`, so the
+    process group is all it needs.  Rank / world / device come from the launcher's environment (torchrun / accelerate
+    launch both export RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)."""
+
+    def __init__(self, backend: Optional[str] = None):
+        import os
+        import torch.distributed as dist
+        self._dist = dist
+        self.num_processes = int(os.environ.get("WORLD_SIZE", 1))
+        self.process_index = int(os.environ.get("RANK", 0))
+        self.local_process_index = int(os.environ.get("LOCAL_RANK", 0))
+        backend = backend or os.environ.get("AURORA_DIST_BACKEND", "nccl")
+        self.backend = backend
+        if self.num_processes > 1 and not dist.is_initialized():
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_process_index)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_process_index))
+            else:
+                dist.init_process_group(backend)
+        self.device = torch.device("cuda", self.local_process_index) if backend == "nccl" else torch.device("cpu")
+
+    is_main_process = property(lambda self: self.process_index == 0)
+    is_local_main_process = property(lambda self: self.local_process_index == 0)
+
+    def gather(self, t: torch.Tensor) -> torch.Tensor:
+        """accelerate's gather: tensors of every rank concatenated along dim 0 (a 0-dim tensor counts as [1])."""
+        src = t.reshape(1) if t.dim() == 0 else t
+        if self.num_processes == 1:
+            return src.clone()
+        home = src.device
+        buf = src.to(self.device).contiguous()
+        out = [torch.empty_like(buf) for _ in range(self.num_processes)]
+        self._dist.all_gather(out, buf)
+        return torch.cat(out, 0).to(home)
+
+    def wait_for_everyone(self) -> None:
+        if self.num_processes > 1:
+            self._dist.barrier()

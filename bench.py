@@ -111,11 +111,31 @@ def cpu_baseline(cfg, args, n_kept):
                 ttft_s=ttft, s_per_caption=total)
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: re-exec this command line as N ranks of ONE node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), exactly the launch the driver uses.  Rank 0's
+    JSON line passes through on stdout.  Mirrors the reference harness's one-process-per-GPU `accelerate launch`
+    (lmms_eval/utils.py:675-681 shard, evaluator.py:519-546 gather)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     # AURORA_DIST_BACKEND=gloo is a TEST hook: it lets `torchrun --nproc-per-node 2 bench.py --gpus 2 --tiny` exercise the
     # multi-rank control flow on a one-GPU box (ranks share the device, collectives carry CPU tensors).  Default: RCCL.
     backend = os.environ.get("AURORA_DIST_BACKEND", "nccl")
@@ -126,9 +146,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: {world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}")
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank, (dist.get_world_size(), args.gpus)
+        # one real collective before any timing: every rank contributes its GPU ordinal, all must be distinct under RCCL
+        probe = torch.tensor([local], dtype=torch.int32, device=(f"cuda:{local}" if backend == "nccl" else "cpu"))
+        seen = [torch.empty_like(probe) for _ in range(world)]
+        dist.all_gather(seen, probe)
+        gpus_seen = sorted(int(t.item()) for t in seen)
+        if backend == "nccl":
+            assert gpus_seen == list(range(world)), f"ranks are not bound one per GPU: {gpus_seen}"
     from aurora_amd import parallel
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup, tokens_at_layer, tome_r
@@ -291,6 +321,7 @@ def main():
         result = {
             "metric": "captions/sec (AuroraCap-7B, 8-frame clips, token_kept_ratio 0.3, 256 new tokens) + p50 TTFT",
             "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else (0 if world > 1 else 1), "dist_backend": backend if world > 1 else "none",
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[1])"

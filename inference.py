@@ -61,9 +61,6 @@ def main():
         if not osp.isdir(args.model_path):
             from huggingface_hub import snapshot_download
             args.model_path = snapshot_download(repo_id=args.model_path)
-        max_ctx = 128 + args.num_frm * 729 + args.max_new_tokens
-        model = AuroraModel.from_pretrained(args.model_path, max_frames=max(args.num_frm + 1, 2), max_ctx=max_ctx,
-                                            max_new_tokens=args.max_new_tokens)
         if args.host_preprocess:      # the reference's host path (PIL); default is the bit-identical HIP input stage
             image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=378, crop_size=378)
 
@@ -89,6 +86,13 @@ def main():
         else:
             sys.exit("error: --visual_input must end with mp4, png or jpg")
         data["input_ids"] = process_text(build_prompt(args.prompt, n_img), tokenizer)
+        # The engine's capacity comes from THIS request: read_video_pyav may return num_frm + 1 frames and the
+        # prompt length is only known after tokenising, so size the context from the spliced length, not from the flags.
+        n_text = int((data["input_ids"] != -200).sum())
+        per_frame = (378 // 14) ** 2                                      # upper bound: token_kept_ratio = 1.0 keeps all patches
+        max_ctx = -(-(n_text + n_img * per_frame + args.max_new_tokens) // 64) * 64
+        model = AuroraModel.from_pretrained(args.model_path, max_frames=max(n_img, 1), max_ctx=max_ctx,
+                                            max_new_tokens=args.max_new_tokens)
 
     model.visual_encoder.reset_tome_r(args.token_kept_ratio)
     output = model(data, mode="inference")

@@ -1,5 +1,7 @@
 """GPU: bench.py in the driver's launch modes (tiny model dims: plumbing, not the metric).
 
+`python bench.py --gpus 2` with NO torchrun environment must launch its own two ranks (self_launch) and report n_gpus 2.
+
 The two-rank case runs `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` exactly as the
 driver does, with AURORA_DIST_BACKEND=gloo so that both ranks can share the single GPU of the test box (collectives
 carry CPU tensors instead of going through RCCL).  It guards the multi-rank control flow: barriers, the per-step result
@@ -36,6 +38,7 @@ def test_single_process_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
+    assert d["rccl_ranks"] == 1 and d["dist_backend"] == "none"
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
 
@@ -51,3 +54,22 @@ def test_two_ranks_torchrun_gloo(extra):
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["clips_per_gpu_per_step"] == 4                       # weak scaling: per-GPU work fixed
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]     # whole-job aggregate
+
+
+def test_gpus_flag_self_launches_ranks_without_torchrun_env():
+    """The driver may run `python bench.py --gpus N` as ONE plain process: bench.py then re-executes itself as N ranks
+    (VERDICT r01 item 1).  gloo lets both ranks share this box's single GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["AURORA_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + TINY, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["value"] > 0
+    assert d["config"]["clips_per_gpu_per_step"] == 4
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    env = dict(os.environ, AURORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + TINY, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

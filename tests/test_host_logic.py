@@ -132,3 +132,42 @@ def test_cli_argument_surface_matches_reference():
     assert (args.num_frm, args.token_kept_ratio, args.temperature, args.top_p, args.num_beams, args.max_new_tokens) == (8, 0.8, 0.0, 1.0, 1, 2048)
     bad = subprocess.run([sys.executable, "inference.py", "--num_beams", "4"], cwd=root, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "greedy" in (bad.stderr + bad.stdout)
+
+
+def _shim_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      AURORA_DIST_BACKEND="gloo")
+    import torch
+    from types import SimpleNamespace
+    from aurora_amd.lmms_plugin.models import auroracap_mi355x as P
+
+    class Tok:
+        bos_token_id, eos_token_id = 1, 2
+
+    lm = P.AuroraCapMI355X(pretrained="unused", device="cpu", batch_size=1, _model=SimpleNamespace(), _tokenizer=Tok(),
+                           _preprocessor=lambda f: f)
+    # what the harness does with the adaptor when world_size > 1 (evaluator.py:426-428, 457)
+    instances_rnk = torch.tensor(3 + lm.rank, device=lm.device)
+    gathered = lm.accelerator.gather(instances_rnk).cpu().detach().numpy().tolist()
+    lm.accelerator.wait_for_everyone()
+    q.put((lm.rank, lm.world_size, gathered))
+    lm.accelerator.wait_for_everyone()
+    torch.distributed.destroy_process_group()
+
+
+def test_lmms_adaptor_provides_the_accelerator_calls_world2():
+    """with WORLD_SIZE > 1 the harness calls lm.accelerator.gather / wait_for_everyone - they must exist."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shim_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, 2, [3, 4]), (1, 2, [3, 4])]

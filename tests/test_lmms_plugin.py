@@ -132,3 +132,83 @@ def test_plugin_loader_contract():
     for name, cls in m.AVAILABLE_MODELS.items():
         mod = importlib.import_module(f"aurora_amd.lmms_plugin.models.{name}")
         assert hasattr(mod, cls)
+
+
+def test_a_failing_request_becomes_an_empty_caption_and_the_rest_go_on():
+    """auroracap.py:511-514: the reference logs the exception and answers "" for that request only."""
+    m = make(batch_size=4)
+    docs = {i: np.zeros((2, 8, 8, 3), np.uint8) for i in range(5)}
+    docs[2] = "clip.avi"                                   # unsupported visual -> load_frames raises
+    m.task_dict = {"vdc": {"test": docs}}
+    reqs = [SimpleNamespace(args=("q%d" % i, {}, lambda d: [d], i, "vdc", "test")) for i in range(5)]
+    out = m.generate_until(reqs)
+    assert out[2] == "" and all(o for i, o in enumerate(out) if i != 2)
+
+    class Flaky(FakeModel):                                # the engine rejects one clip of the batch (e.g. context too long)
+        def caption_batch(self, clips, max_new_tokens=2048):
+            if any(px.shape[0] == 3 for px, _ in clips):
+                raise RuntimeError("seq_len + max_new exceeds max_ctx")
+            return super().caption_batch(clips, max_new_tokens)
+    m2 = P.AuroraCapMI355X(pretrained="unused", device="cpu", batch_size=4, _model=Flaky(), _tokenizer=FakeTok(), _preprocessor=fake_pre)
+    docs2 = {i: np.zeros((3 if i == 1 else 2, 8, 8, 3), np.uint8) for i in range(4)}
+    m2.task_dict = {"vdc": {"test": docs2}}
+    out2 = m2.generate_until([SimpleNamespace(args=("q", {}, lambda d: [d], i, "vdc", "test")) for i in range(4)])
+    assert out2[1] == "" and all(out2[i] for i in (0, 2, 3))
+
+
+def test_stream_mode_reports_rejected_clips_through_on_error():
+    class Streaming(FakeModel):
+        def caption_stream(self, clips, max_new_tokens=2048, on_error=None):
+            for k, (px, ids) in enumerate(clips):
+                if px.shape[0] == 5:
+                    on_error(k, ValueError("too many frames"))
+                else:
+                    yield k, [int(px.shape[0]), k]
+    m = P.AuroraCapMI355X(pretrained="unused", device="cpu", batch_size=2, _model=Streaming(), _tokenizer=FakeTok(), _preprocessor=fake_pre)
+    docs = {0: np.zeros((2, 8, 8, 3), np.uint8), 1: "bad.avi", 2: np.zeros((5, 8, 8, 3), np.uint8), 3: np.zeros((4, 8, 8, 3), np.uint8)}
+    m.task_dict = {"vdc": {"test": docs}}
+    out = m.generate_until([SimpleNamespace(args=("same", {}, lambda d: [d], i, "vdc", "test")) for i in range(4)])
+    # request 1 never reaches the stream (decode failure), request 2 is rejected by the engine; 0 and 3 keep THEIR results
+    assert out == ["2 0", "", "", "4 2"]
+
+
+def test_constructor_plumbing_reaches_from_pretrained_with_config_derived_capacity(tmp_path, monkeypatch):
+    """INTEGRATION.md option C, single process, default device="cuda": the real constructor path with a stub engine
+    (ADVICE r01): capacity comes from visual_encoder/config.json, not from hard-coded ViT-H/14 numbers."""
+    import json
+    import sys
+    import types
+    (tmp_path / "visual_encoder").mkdir()
+    (tmp_path / "visual_encoder" / "config.json").write_text(json.dumps(dict(
+        hidden_size=64, num_attention_heads=4, num_hidden_layers=8, intermediate_size=128, patch_size=16, image_size=64)))
+    seen = {}
+
+    class StubModel:
+        config = None
+
+        @classmethod
+        def from_pretrained(cls, path, **kw):
+            seen.update(kw, path=path)
+            return cls()
+    import aurora_amd.model as M
+    import aurora_amd.preprocess as PP
+    monkeypatch.setattr(M, "AuroraModel", StubModel)
+    monkeypatch.setattr(PP, "FramePreprocessor", lambda image, device: ("pre", image, device))
+    fake_tf = types.ModuleType("transformers")
+    fake_tf.AutoTokenizer = SimpleNamespace(from_pretrained=lambda *a, **k: FakeTok())
+    monkeypatch.setitem(sys.modules, "transformers", fake_tf)
+    m = P.AuroraCapMI355X(pretrained=str(tmp_path), resolution=64, token_merge_ratio=0.5, batch_size=3, max_frames_num=4, max_new_tokens=100)
+    # 64/16 = 4 -> 16 patches + CLS; r = int(16 * 0.5 / 8) = 1 per layer over 7 layers -> 17 - 7 = 10 tokens, 9 without CLS
+    assert seen["max_frames"] == 5 and seen["max_batch"] == 3 and seen["max_new_tokens"] == 100 and seen["device"] == "cuda"
+    assert seen["max_ctx"] == 256 + 5 * 9 + 100
+    assert m.world_size == 1 and not hasattr(m, "accelerator")
+
+
+def test_engine_device_normalisation(monkeypatch):
+    from aurora_amd.engine import AuroraCapEngine
+    from aurora_amd._lib import AuroraHipError
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert AuroraCapEngine.normalize_device("cuda") == torch.device("cuda", 3)        # torch.cuda.set_device needs an index
+    assert AuroraCapEngine.normalize_device("cuda:1") == torch.device("cuda", 1)
+    with pytest.raises(AuroraHipError):
+        AuroraCapEngine.normalize_device("cpu")

@@ -63,7 +63,10 @@ def main():
             print(f"{tag:28s} {k:12s} {us:9.2f} us  {rate:9.1f} {unit}", flush=True)
 
     dec = ["dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
-    run("decode", dec)
+    for variant, tag in ((0, "decode x-per-wave"), (1, "decode x-through-LDS")):
+        eng.set_option("skinny_variant", variant)
+        run(tag, dec)
+    eng.set_option("skinny_variant", 1 if B > 32 else 0)
     if not args.quick:
         for nw in (4, 8):
             eng.set_option("dec_row_waves", nw)
