@@ -13,6 +13,7 @@
 //  * MFMA 16x16x32 C/D map (guide section 3): lane holds D[row = 4*(lane>>4) + i][col = lane & 15], i = 0..3.
 #pragma once
 #define AUR_MAX_BATCH 64     /* decode slots per bank: up to 4 MFMA column groups of 16 batch rows */
+#define AUR_SSQ_SLOTS 16     /* stripes of the sum(x^2) accumulators (power of two): decode.hip ssq_to_rstd */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -35,22 +35,64 @@ __device__ __forceinline__ int64_t xfrag_piece(int b, int k, int K32) {
 }
 
 #define SSQ_SCALE 268435456.0f      /* 2^28 */
-__device__ __forceinline__ float ssq_to_rstd(unsigned long long s, int k, float eps) {
+// sum(x^2) accumulators are striped over AUR_SSQ_SLOTS copies, [slot][AUR_MAX_BATCH]: the residual-producing epilogues add into
+// slot (n16 tile % SLOTS), so the 256 integer atomics that hit one row's accumulator per projection spread over 16 L2 lines
+// instead of queueing on one (they cost the o / down projections ~5 us each at 64 rows: 18.4 us in the engine vs 13.7 us with a
+// plain store epilogue, tools/gemv_lab); the consumer adds the slots - integers: any order gives the same bits.
+__device__ __forceinline__ float ssq_to_rstd(const unsigned long long* ssq, int b, int k, float eps) {
+    unsigned long long s = 0ull;
+#pragma unroll
+    for (int sl = 0; sl < AUR_SSQ_SLOTS; ++sl) s += ssq[sl * AUR_MAX_BATCH + b];
     return rsqrtf((float)((double)s * (1.0 / 268435456.0)) / (float)k + eps);
+}
+__device__ __forceinline__ void ssq_set(unsigned long long* ssq, int b, unsigned long long v) {        // one writer per row
+    ssq[b] = v;
+#pragma unroll
+    for (int sl = 1; sl < AUR_SSQ_SLOTS; ++sl) ssq[sl * AUR_MAX_BATCH + b] = 0ull;
+}
+__device__ __forceinline__ void ssq_clear(unsigned long long* ssq, int tid) {                          // tid < AUR_MAX_BATCH
+#pragma unroll
+    for (int sl = 0; sl < AUR_SSQ_SLOTS; ++sl) ssq[sl * AUR_MAX_BATCH + tid] = 0ull;
 }
 
 // Epilogue shared by every skinny-GEMM structure: the lane holds acc[t][nb][i] = y[n = (tile0 + t) * 16 + 4g + i][b = nb * 16 + c]
 // (MFMA 16x16x32 C/D map), already reduced over K.  SK_QKV: a Q / K workgroup-unit is one PAIRED 32-column block (NT == 2:
 // tiles 2p and 2p + 1 hold d and its RoPE partner d + hd/2); a V unit is NT consecutive n16 tiles.
+// Per-lane inputs of the epilogue that do not depend on the projection itself (this lane's batch rows b = nb * 16 + c): loaded
+// BEFORE the weight stream starts, so that their L2 round trips (16 accumulator stripes per row, then position -> page table)
+// hide under it instead of serialising behind the last MFMA (measured at B = 64: 2-3 us per launch on the QKV / gate-up kernels).
+template <int NB>
+struct SkPre {
+    float rstd[NB];
+    int pos[NB];
+    half_t* page[NB];
+};
+template <int MODE, int NB>
+__device__ __forceinline__ void skinny_prefetch(const SkinnyArgs& a, const int lane, SkPre<NB>& pre, const int tile0 = 0) {
+    const int c = lane & 15;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = nb * 16 + c;
+        const bool live = b >= a.b_lo && b < a.b_hi;
+        pre.rstd[nb] = (a.ssq_in && live) ? ssq_to_rstd(a.ssq_in, b, a.K, a.norm_eps) : 1.f;
+        pre.pos[nb] = 0;
+        pre.page[nb] = nullptr;
+        if (MODE == SK_QKV && live) {
+            pre.pos[nb] = a.pos[b];
+            pre.page[nb] = kv_page(a.kv, a.seq_ids ? a.seq_ids[b] : b, pre.pos[nb]);
+        }
+    }
+}
+
 template <int NT, int MODE, int NB>
-__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile0, f4 (&acc)[NT][NB], const int lane) {
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile0, f4 (&acc)[NT][NB], const int lane, const SkPre<NB>& pre) {
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int b = nb * 16 + c;
         if (b < a.b_lo || b >= a.b_hi) continue;
         if (a.ssq_in) {                                   // folded RMSNorm: per-row 1/rms of the (un-normalised) input
-            const float rstd = ssq_to_rstd(a.ssq_in[b], a.K, a.norm_eps);
+            const float rstd = pre.rstd[nb];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -63,8 +105,12 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile
                 const int n = tile * 16 + 4 * g;
                 if (n >= a.n_real) continue;
                 if (MODE == SK_LOGITS) {
+                    float* dst = a.out32 + (int64_t)b * a.n_real + n;
+                    if ((a.n_real & 3) == 0) *(f4*)dst = acc[t][nb];      // n % 4 == 0: one 16-byte store
+                    else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a.out32[(int64_t)b * a.n_real + n + i] = acc[t][nb][i];
+                        for (int i = 0; i < 4; ++i) dst[i] = acc[t][nb][i];
+                    }
                 } else if (MODE == SK_SILU_MUL) {
                     // h[b][k], k = n/2 + {0,1} = tile*8 + 2g + {0,1}, written in x-fragment form for the down projection
                     h2 o;
@@ -86,21 +132,23 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile
                     *(h4*)px = o;
                     p += __shfl_xor(p, 16, 64);
                     p += __shfl_xor(p, 32, 64);
-                    if (g == 0 && a.ssq_out) atomicAdd(a.ssq_out + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
+                    if (g == 0 && a.ssq_out)
+                        atomicAdd(a.ssq_out + (tile & (AUR_SSQ_SLOTS - 1)) * AUR_MAX_BATCH + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
                 }
             }
         } else {                  // SK_QKV: one PAIRED 32-column block (Q / K, NT == 2) or NT n16 tiles of V
             const KvLayout& kv = a.kv;
             const int nbc = tile0 * 16;
-            const int pos = a.pos[b];
-            const int seq = a.seq_ids ? a.seq_ids[b] : b;
-            half_t* page = kv_page(kv, seq, pos);
+            const int pos = pre.pos[nb];
+            half_t* page = pre.page[nb];
             if (nbc < a.q_cols + a.k_cols) {
                 const bool is_q = nbc < a.q_cols;
                 const int nreg = is_q ? nbc : nbc - a.q_cols;
                 const int blkg = nreg >> 5;
                 const int head = blkg / kv.kblk, blk = blkg % kv.kblk;
                 if (head >= kv.heads) continue;
+                // (cos, sin) stay in the epilogue: prefetching them is a THIRD dependent round trip (pos -> table) queued ahead of the
+                // weight stream's in-order vmcnt - measured +10 us on this kernel
                 const float2* cs = a.rope + (int64_t)pos * (a.hd >> 1) + blk * 16 + 4 * g;
                 h8 o;
 #pragma unroll
@@ -135,9 +183,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.ssq_zero && blockIdx.x == 0 && tid < AUR_MAX_BATCH) a.ssq_zero[tid] = 0ull;     // reset the accumulator a LATER kernel fills
+    if (a.ssq_zero && blockIdx.x == 0 && tid < AUR_MAX_BATCH) ssq_clear(a.ssq_zero, tid);  // reset the accumulator a LATER kernel fills
     const int K32 = a.K >> 5;
     const int tile0 = blockIdx.x * NT;
+    SkPre<NB> pre;
+    if (w == 0) skinny_prefetch<MODE, NB>(a, lane, pre, tile0);                            // wave 0 runs the epilogue
 
     f4 acc[NT][NB];
 #pragma unroll
@@ -270,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
             acc[t][nb] = s;
         }
 
-    skinny_store<NT, MODE, NB>(a, tile0, acc, lane);
+    skinny_store<NT, MODE, NB>(a, tile0, acc, lane, pre);
 }
 
 // ------------------------------------------------------------------------------------ skinny GEMM, x through LDS
@@ -324,7 +374,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = blockIdx.x, s = blockIdx.y;
-    if (a.ssq_zero && c == 0 && s == 0 && tid < AUR_MAX_BATCH) a.ssq_zero[tid] = 0ull;    // reset the accumulator a LATER kernel fills
+    if (a.ssq_zero && c == 0 && s == 0 && tid < AUR_MAX_BATCH) ssq_clear(a.ssq_zero, tid); // reset the accumulator a LATER kernel fills
     const int K32 = a.K >> 5, KE = K32 / gm.S, kb = s * KE;
     const int nchunk = (KE + KC - 1) / KC;
 
@@ -371,6 +421,8 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + t;
     }
     if (t >= ntile) return;                                    // idle consumer (ended waves do not count at s_barrier)
+    SkPre<NB> pre;
+    if (p == 0 && !(MODE == SK_ROW && gm.S > 1)) skinny_prefetch<MODE, NB>(a, lane, pre, tile);  // the waves that run the epilogue
     f4 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -441,7 +493,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
             f4 pr[2][NB];
             gather(0, pr[0]);
             gather(KS, pr[1]);
-            skinny_store<2, MODE, NB>(a, tile, pr, lane);
+            skinny_store<2, MODE, NB>(a, tile, pr, lane, pre);
             return;
         }
         gather(w, acc);
@@ -455,7 +507,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     f4 one[1][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) one[0][nb] = acc[nb];
-    skinny_store<1, MODE, NB>(a, tile, one, lane);
+    skinny_store<1, MODE, NB>(a, tile, one, lane, pre);
 }
 
 // second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue
@@ -465,6 +517,8 @@ __global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, Sk
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int N16 = a.Npad >> 4;
     if (tile >= N16) return;
+    SkPre<NB> pre;
+    skinny_prefetch<SK_ROW, NB>(a, lane, pre);
     f4 acc[1][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[0][nb] = *(const f4*)(gm.part + (((int64_t)tile * NB + nb) * 64 + lane) * 4);
@@ -476,7 +530,7 @@ __global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, Sk
             for (int i = 0; i < 4; ++i) acc[0][nb][i] += q[i];
         }
     }
-    skinny_store<1, SK_ROW, NB>(a, tile, acc, lane);
+    skinny_store<1, SK_ROW, NB>(a, tile, acc, lane, pre);
 }
 
 static int g_skx_cus = 256;
@@ -515,6 +569,7 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             const int pairs = (a.q_cols + a.k_cols) >> 5;
             gm.v_tile0 = (a.q_cols + a.k_cols) >> 4;
             if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
+            if (a.waves == 2) return launch_skx_t<3, 4, SK_QKV, NB, 8, 4, 2, 4>(a, gm, dim3(pairs, 1), s);
             return launch_skx_t<3, 4, SK_QKV, NB, 8, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
         case SK_SILU_MUL: return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
@@ -629,7 +684,7 @@ __global__ __launch_bounds__(64 * NWV) void xfrag_norm_kernel(const half_t* __re
         ss = wave_sum(ss);
         if (lane == 0) {
             rs[rr] = w ? rsqrtf(ss / (float)d + eps) : 1.f;
-            if (ssq_out && row >= 0 && row < rows) ssq_out[b] = (unsigned long long)__float2ll_rn(ss * SSQ_SCALE);
+            if (ssq_out && row >= 0 && row < rows) ssq_set(ssq_out, b, (unsigned long long)__float2ll_rn(ss * SSQ_SCALE));
         }
     }
     __syncthreads();
@@ -997,7 +1052,7 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(const float* __rest
         if (tid < o) sv[tid] += sv[tid + o];
         __syncthreads();
     }
-    if (tid == 0) ssq[b] = (unsigned long long)__float2ll_rn(sv[0] * SSQ_SCALE);
+    if (tid == 0) ssq_set(ssq, b, (unsigned long long)__float2ll_rn(sv[0] * SSQ_SCALE));
 }
 
 hipError_t launch_argmax_advance(const float* logits, int b0, int nb, int vocab, const half_t* embed, int d, int eos_id,

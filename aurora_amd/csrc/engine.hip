@@ -69,7 +69,7 @@ struct aur_ctx {
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
-    int skinny_variant = 0, row_split_min_k = 8192;                             // decode projections: x through LDS (engines of > 32 slots)
+    int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
@@ -229,8 +229,8 @@ static int64_t carve(aur_ctx* c, char* base) {
     for (int bk = 0; bk < 2; ++bk) {
         aur_ctx::Bank& K = c->banks[bk];
         K.d_x = k.take<half_t>(Bp * d);                    // residual stream    (x-fragment form)
-        K.s_ssq_mlp = k.take<unsigned long long>(AUR_MAX_BATCH);      // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
-        K.s_ssq_attn = k.take<unsigned long long>(AUR_MAX_BATCH);     // sum(x^2) per row after the attention residual
+        K.s_ssq_mlp = k.take<unsigned long long>(AUR_SSQ_SLOTS * AUR_MAX_BATCH);      // sum(x^2) per row after the MLP / embedding (2^-28 fixed point)
+        K.s_ssq_attn = k.take<unsigned long long>(AUR_SSQ_SLOTS * AUR_MAX_BATCH);     // sum(x^2) per row after the attention residual
         K.d_logits = k.take<float>(B * g.llm_vocab);
         K.s_pos = k.take<int32_t>(B);
         K.s_ids = k.take<int32_t>(B * g.max_new_tokens);
@@ -791,8 +791,8 @@ extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_toke
     CK(hipMemsetAsync(ctx->s_ids, 0, (size_t)g.max_batch * g.max_new_tokens * 4, s));
     const size_t bp = (size_t)rup(g.max_batch, 16);       // unused fragment lanes must hold finite values
     CK(hipMemsetAsync(ctx->d_x, 0, bp * g.llm_hidden * 2, s));          // bank-owned buffers only: the other bank may be decoding
-    CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, AUR_MAX_BATCH * 8, s));
-    CK(hipMemsetAsync(ctx->s_ssq_attn, 0, AUR_MAX_BATCH * 8, s));
+    CK(hipMemsetAsync(ctx->s_ssq_mlp, 0, AUR_SSQ_SLOTS * AUR_MAX_BATCH * 8, s));
+    CK(hipMemsetAsync(ctx->s_ssq_attn, 0, AUR_SSQ_SLOTS * AUR_MAX_BATCH * 8, s));
     return AUR_OK;
 }
 
@@ -886,7 +886,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.waves = ctx->qkv_depth;
     return q;
 }
 static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
@@ -1038,6 +1038,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
+    else if (!strcmp(name, "skinny_qkv_depth")) ctx->qkv_depth = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
     else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);

@@ -114,9 +114,9 @@ struct SkinnyArgs {
     int waves;              // SK_ROW: 4 (default) or 8 waves per workgroup
     int b_lo, b_hi;         // only batch columns b_lo <= b < b_hi are stored
     half_t* xres;           // SK_ROW: residual stream in x-fragment form (K32 = n_real/32), updated in place: x += y
-    unsigned long long* ssq_out;        // SK_ROW: sum(x_new^2) per row, 2^-28 fixed point, accumulated with integer atomics
+    unsigned long long* ssq_out;        // SK_ROW: sum(x_new^2) per row [AUR_SSQ_SLOTS][AUR_MAX_BATCH], 2^-28 fixed point, integer atomics
     const unsigned long long* ssq_in;   // folded RMSNorm: sum(x^2) of the input rows -> acc *= rsqrt(ssq/K + eps); nullptr = none
-    unsigned long long* ssq_zero;       // accumulator (32 entries) to reset for a later kernel; nullptr = none
+    unsigned long long* ssq_zero;       // accumulator (all slots) to reset for a later kernel; nullptr = none
     float norm_eps;
     half_t* out_f;          // SK_SILU_MUL: x-fragment form with K32 = out_k32 (input of the down projection)
     int out_k32;

@@ -5,6 +5,9 @@ Shapes follow the checkpoints named by the reference configs:
   language model  lmsys/vicuna-7b-v1.5-16k        (auroracap_7b_language_stage.py:37; RoPE linear x4)
 Recipe: Linear / conv / embedding weights N(0, 0.02^2), LayerNorm / RMSNorm weight 1, bias 0,
 fp16, seeded.  Frames: uint8 U[0,255], CLIP mean/std normalisation (inference.py:58-63 processor).
+`norm_std` / `bias_std` > 0 (parity tests only; the benchmark keeps the recipe above) draw the norm weights as
+1 + N(0, norm_std^2) and every bias as N(0, bias_std^2) from a SEPARATE generator, so the matrices stay those of the
+recipe: a real checkpoint's norm weights are far from 1, and the decode path folds them into the projections.
 """
 from __future__ import annotations
 
@@ -26,12 +29,19 @@ def _rn(gen, *shape, std=0.02, device="cuda"):
     return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * std).to(torch.float16)
 
 
-def vit_weights(cfg, seed=1234, device="cuda", num_layers=None):
+def _norm_like(gen, n, mean, std, device):
+    if std <= 0:
+        return torch.full((n,), mean, dtype=torch.float16, device=device)
+    return (mean + torch.randn(n, generator=gen, device=device, dtype=torch.float32) * std).to(torch.float16)
+
+
+def vit_weights(cfg, seed=1234, device="cuda", num_layers=None, norm_std=0.0, bias_std=0.0):
     g = torch.Generator(device=device).manual_seed(seed)
+    g2 = torch.Generator(device=device).manual_seed(seed + 7777)
     D, mlp, P, C = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"], cfg.get("num_channels", 3)
     t0 = (cfg["image_size"] // P) ** 2 + 1
-    one = lambda n: torch.ones(n, dtype=torch.float16, device=device)
-    zero = lambda n: torch.zeros(n, dtype=torch.float16, device=device)
+    one = lambda n: _norm_like(g2, n, 1.0, norm_std, device)
+    zero = lambda n: _norm_like(g2, n, 0.0, bias_std, device)
     w = {"patch_embedding.weight": _rn(g, D, C, P, P, device=device), "class_embedding": _rn(g, D, device=device),
          "position_embedding.weight": _rn(g, t0, D, device=device), "pre_layrnorm.weight": one(D), "pre_layrnorm.bias": zero(D),
          "layers": []}
@@ -54,10 +64,11 @@ def projector_weights(dv, d, seed=1235, device="cuda"):
             "model.2.weight": _rn(g, d, d, device=device), "model.2.bias": z(d)}
 
 
-def llm_weights(cfg, seed=1236, device="cuda", num_layers=None):
+def llm_weights(cfg, seed=1236, device="cuda", num_layers=None, norm_std=0.0):
     g = torch.Generator(device=device).manual_seed(seed)
+    g2 = torch.Generator(device=device).manual_seed(seed + 7777)
     d, mlp, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
-    one = lambda n: torch.ones(n, dtype=torch.float16, device=device)
+    one = lambda n: _norm_like(g2, n, 1.0, norm_std, device)
     w = {"embed_tokens.weight": _rn(g, V, d, device=device), "norm.weight": one(d), "lm_head.weight": _rn(g, V, d, device=device),
          "layers": []}
     for _ in range(cfg["num_hidden_layers"] if num_layers is None else num_layers):

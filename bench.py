@@ -62,53 +62,92 @@ def parse():
 
 
 def cpu_baseline(cfg, args, n_kept):
-    """Oracle (CPU port of the reference path, oracle/aurora_oracle.py) timed on the host cores on a bounded sample
-    of the same workload, extrapolated linearly to one caption."""
+    """SURVEY 8d "CPU baseline beside it": the oracle (oracle/aurora_oracle.py, the PyTorch-CPU fp32 port of the reference
+    path; the reference's own Python cannot run on the GPU box) timed on this box's host cores on
+      * configs[1] (the bench workload): ViT + per-layer ToMe on ALL frames, projector + splice and the Llama prefill IN
+        FULL (32 layers), then 16 greedy decode tokens, extrapolated linearly to max_new_tokens (stated), and
+      * configs[0] (1 frame, token_kept_ratio 1.0, 32 tokens): in full.
+    Runs after the timed region on rank 0 only.  A host with too little free memory for the fp32 weights (27 GB) falls back to a
+    bounded layer sample and says so."""
+    import platform
     from aurora_amd import synthetic as S
     from oracle import aurora_oracle as O
     torch.set_grad_enabled(False)
     cores = torch.get_num_threads()
+    cpu_model = platform.processor() or "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     v, l = cfg["vit"], cfg["llm"]
     f32 = lambda d: {k: ([f32(x) for x in val] if isinstance(val, list) else val.float().cpu()) for k, val in d.items()}
-    # --- vision sample: 1 frame through the real-depth tower (31 of 32 layers, per-layer ToMe) ---------------
-    vw = f32(S.vit_weights(v, device="cuda"))
-    px = S.frames(1, 0, v["image_size"]).float().cpu()
-    t0 = time.perf_counter()
-    feats = O.vit_features(px, vw, v, args.token_kept_ratio)
-    t_vit1 = time.perf_counter() - t0
-    assert feats.shape[1] == n_kept
-    del vw
-    # --- language sample: 2 of 32 layers at real width, prefill L0 + 4 decode tokens, lm_head per token -------
-    nl = 2
-    lw = f32(S.llm_weights(l, device="cuda", num_layers=nl))
-    L0 = 30 + args.num_frm * n_kept
-    emb = torch.randn(L0, l["hidden_size"]) * 0.02
+    nl_full = l["num_hidden_layers"]
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2**30
+    except Exception:
+        free_gb = 0.0
+    need_gb = 4.0 * (nl_full * (4 * l["hidden_size"] ** 2 + 3 * l["hidden_size"] * l["intermediate_size"]) + 2 * l["vocab_size"] * l["hidden_size"]) / 2**30
+    nl = nl_full if free_gb > 1.5 * need_gb + 16 else 2
+    wdev = "cuda" if torch.cuda.is_available() else "cpu"               # same generator stream as the engine's weights
+    vw = f32(S.vit_weights(v, device=wdev))
+    pw = f32(S.projector_weights(v["hidden_size"], l["hidden_size"], device=wdev))
+    lw = f32(S.llm_weights(l, device=wdev, num_layers=nl))
+    if wdev == "cuda":
+        torch.cuda.empty_cache()
     sub = dict(l, num_hidden_layers=nl)
-    t0 = time.perf_counter()
-    h, kv = O.llama_forward(emb, lw, sub, None, 0)
-    t_pre = time.perf_counter() - t0
-    ndec = 4
-    t0 = time.perf_counter()
-    pos = L0
-    for _ in range(ndec):
+    scale = nl_full / nl
+
+    def caption(frames_n, ratio, n_dec, clip):
+        """-> (seconds: vision, project+splice, prefill, per decoded token [measured over n_dec tokens]), prefix length."""
+        px = S.frames(frames_n, clip, v["image_size"], device="cpu").float()
+        ids = S.prompt_ids(frames_n, clip, 30, l["vocab_size"])
+        t0 = time.perf_counter()
+        feats = O.vit_features(px, vw, v, ratio)
+        t1 = time.perf_counter()
+        f, n, dv = feats.shape
+        vis = O.projector(feats.reshape(1, f * n, dv), pw).reshape(f, n, -1)
+        emb = O.splice(torch.tensor(ids), lw["embed_tokens.weight"], vis)
+        t2 = time.perf_counter()
+        h, kv = O.llama_forward(emb, lw, sub, None, 0)
         logits = torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
-        nxt = int(logits.argmax())
-        h, kv = O.llama_forward(lw["embed_tokens.weight"][nxt][None], lw, sub, kv, pos)
-        pos += 1
-    t_dec = (time.perf_counter() - t0) / ndec
-    scale = l["num_hidden_layers"] / nl
-    t0 = time.perf_counter()
-    torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
-    t_lm_head = time.perf_counter() - t0          # once per token, not scaled by the layer count
-    per_tok = (t_dec - t_lm_head) * scale + t_lm_head
-    ttft = t_vit1 * args.num_frm + t_pre * scale
-    total = ttft + per_tok * (args.max_new_tokens - 1)
-    return dict(value=1.0 / total, unit="captions/s", cores=cores, kind="port",
-                sample=(f"oracle (PyTorch-CPU fp32 port, {cores} threads) at real dims: ViT+ToMe on 1 of {args.num_frm} frames "
-                        f"({t_vit1:.2f}s), Llama prefill of {L0} tokens + {ndec} decode tokens through {nl} of "
-                        f"{l['num_hidden_layers']} layers ({t_pre:.2f}s, {t_dec:.3f}s/token); extrapolated linearly to "
-                        f"{args.num_frm} frames, {l['num_hidden_layers']} layers, {args.max_new_tokens} tokens"),
-                ttft_s=ttft, s_per_caption=total)
+        nxt = int(logits.argmax())                                     # first token: end of TTFT
+        t3 = time.perf_counter()
+        pos = emb.shape[0]
+        for _ in range(n_dec):
+            h, kv = O.llama_forward(lw["embed_tokens.weight"][nxt][None], lw, sub, kv, pos)
+            nxt = int(torch.nn.functional.linear(h[-1:], lw["lm_head.weight"]).argmax())
+            pos += 1
+        t4 = time.perf_counter()
+        t_lm = 0.0
+        if nl != nl_full:                                              # layer sample: the lm_head does not scale with depth
+            t5 = time.perf_counter()
+            torch.nn.functional.linear(h[-1:], lw["lm_head.weight"])
+            t_lm = time.perf_counter() - t5
+        per_tok = ((t4 - t3) / max(n_dec, 1) - t_lm) * scale + t_lm
+        return dict(vision_s=t1 - t0, project_s=t2 - t1, prefill_s=(t3 - t2 - t_lm) * scale + t_lm, s_per_token=per_tok, prefix=emb.shape[0])
+
+    ndec = 16
+    c2 = caption(args.num_frm, args.token_kept_ratio, ndec, 0)
+    assert c2["prefix"] == 30 + args.num_frm * n_kept
+    ttft2 = c2["vision_s"] + c2["project_s"] + c2["prefill_s"]
+    total2 = ttft2 + c2["s_per_token"] * (args.max_new_tokens - 1)
+    c1 = caption(1, 1.0, 31, 1)                                         # configs[0]: 1 frame, ratio 1.0, 32 tokens, in full
+    ttft1 = c1["vision_s"] + c1["project_s"] + c1["prefill_s"]
+    total1 = ttft1 + c1["s_per_token"] * 31
+    depth = "all %d layers" % nl_full if nl == nl_full else "%d of %d Llama layers (host has %.0f GB free, fp32 weights need %.0f GB), scaled by depth" % (nl, nl_full, free_gb, need_gb)
+    return dict(value=1.0 / total2, unit="captions/s", cores=cores, kind="port", cpu_model=cpu_model,
+                sample=(f"oracle (PyTorch-CPU fp32 port of the reference path, {cores} threads, {cpu_model}): configs[1] one clip - ViT + ToMe on all "
+                        f"{args.num_frm} frames {c2['vision_s']:.1f}s, projector + splice {c2['project_s']:.2f}s, Llama prefill of {c2['prefix']} tokens "
+                        f"{c2['prefill_s']:.1f}s, {ndec} decode tokens at {c2['s_per_token']:.3f}s/token, {depth}; decode extrapolated linearly from "
+                        f"{ndec} to {args.max_new_tokens - 1} steps"),
+                ttft_s=ttft2, s_per_caption=total2,
+                configs0={"workload": "1 frame, token_kept_ratio 1.0, greedy 32 tokens (BASELINE configs[0]), timed in full",
+                          "s_per_caption": total1, "ttft_s": ttft1, "captions_per_s": 1.0 / total1, "prefix": c1["prefix"],
+                          "vision_s": c1["vision_s"], "prefill_s": c1["prefill_s"], "s_per_token": c1["s_per_token"]})
 
 
 def self_launch(n: int) -> int:

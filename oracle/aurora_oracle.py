@@ -380,7 +380,7 @@ def llama_greedy(embeds, lw, cfg, max_new_tokens: int, eos_id: Optional[int] = 2
 # whole path: AuroraModel.forward(mode="inference") + generate  (aurora.py:214-270)
 # --------------------------------------------------------------------------
 def caption_ids(pixels, input_ids, weights, cfg, token_kept_ratio, max_new_tokens,
-                eos_id: Optional[int] = 2, q: Q = None, timings: Optional[dict] = None):
+                eos_id: Optional[int] = 2, q: Q = None, timings: Optional[dict] = None, return_logits: bool = False):
     """pixels [f,3,H,W] fp32 (already normalised), input_ids list[int] with -200 markers."""
     import time
     t0 = time.perf_counter()
@@ -389,8 +389,8 @@ def caption_ids(pixels, input_ids, weights, cfg, token_kept_ratio, max_new_token
     vis = projector(feats.reshape(1, f * n, dv), weights["projector"], q).reshape(f, n, -1)
     emb = splice(torch.tensor(input_ids), weights["llm"]["embed_tokens.weight"], vis)
     t1 = time.perf_counter()
-    ids = llama_greedy(emb, weights["llm"], cfg["llm"], max_new_tokens, eos_id, q)
+    ids, logits = llama_greedy(emb, weights["llm"], cfg["llm"], max_new_tokens, eos_id, q, return_logits=True)
     t2 = time.perf_counter()
     if timings is not None:
         timings.update(vision_s=t1 - t0, llm_s=t2 - t1, prefill_len=emb.shape[0])
-    return ids
+    return (ids, logits) if return_logits else ids

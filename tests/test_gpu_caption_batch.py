@@ -15,11 +15,15 @@ VCFG = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=4, intermed
             image_size=56, hidden_act="quick_gelu", layer_norm_eps=1e-5)
 
 
+def weights():
+    lcfg = LLM_CFGS["hd32"]
+    return {"vit": rand_vit_weights(VCFG, 1), "projector": rand_proj_weights(64, lcfg["hidden_size"], 2), "llm": rand_llm_weights(lcfg, 3)}
+
+
 def build(max_batch, max_new=16):
     from aurora_amd.engine import AuroraCapEngine
-    lcfg = LLM_CFGS["hd32"]
-    w = {"vit": rand_vit_weights(VCFG, 1), "projector": rand_proj_weights(64, lcfg["hidden_size"], 2), "llm": rand_llm_weights(lcfg, 3)}
-    return AuroraCapEngine({"vit": VCFG, "llm": lcfg}, w, max_frames=4, max_batch=max_batch, max_ctx=512, max_new_tokens=max_new)
+    return AuroraCapEngine({"vit": VCFG, "llm": LLM_CFGS["hd32"]}, weights(), max_frames=4, max_batch=max_batch, max_ctx=512,
+                           max_new_tokens=max_new)
 
 
 def clips(n, seed):
@@ -127,5 +131,54 @@ def test_caption_stream_continuous_batching():
         assert lens.tolist() == [6, 6] and fin.tolist() == [1, 1]
         with pytest.raises(Exception):
             eng.slot_reset(2)
+    finally:
+        eng.close()
+
+
+def test_stream_and_adaptor_against_the_oracle_with_eos():
+    """f2 / f3 against the ORACLE, not against the engine itself: continuous batching with EOS stopping
+    and the lmms-eval adaptor must give each clip the oracle's greedy ids (CPU port of the reference path, fp16-storage
+    emulation) up to the first position whose oracle margin is inside the logit tolerance - and stop at the same EOS."""
+    from oracle import aurora_oracle as O
+    from aurora_amd.lmms_plugin.models import auroracap_mi355x as P
+    from aurora_amd.model import AuroraModel
+    from tests.test_gpu_llm import LOGIT_TOL, assert_greedy_agrees_up_to_margin
+    from tests.test_lmms_plugin import FakeTok
+    cfg = {"vit": VCFG, "llm": LLM_CFGS["hd32"]}
+    w = weights()
+    cs = clips(7, 21)
+    N = 14
+    free = [O.caption_ids(px.float(), ids, w, cfg, 0.5, N, eos_id=None, q=O.fp16_storage, return_logits=True) for px, ids in cs]
+    eos = free[2][0][4]                                                          # occurs in clip 2's caption -> ragged stopping
+    want = [(ids[: ids.index(eos) + 1] if eos in ids else ids, lg) for ids, lg in free]      # HF semantics: the EOS itself is emitted
+    assert len({len(x[0]) for x in want}) > 1
+
+    def safe(ids, logits):                                                       # every margin clear of the tolerance?
+        scale = logits.abs().max().item()
+        return all((logits[i].topk(2).values[0] - logits[i].topk(2).values[1]).item() > 2 * LOGIT_TOL * scale for i in range(len(ids)))
+
+    eng = build(max_batch=3, max_new=N)
+    try:
+        got = dict(eng.caption_stream(cs, 0.5, N, eos_id=eos, check_every=4))
+        assert sorted(got) == list(range(7))
+        n_exact = 0
+        for i, (ids, lg) in enumerate(want):
+            assert_greedy_agrees_up_to_margin(got[i], ids, lg)
+            if safe(ids, lg):
+                assert got[i] == ids, i                                          # same tokens AND the same stopping point
+                n_exact += 1
+        assert n_exact >= 3, n_exact
+        # the adaptor end to end: HIP input stage is bypassed (frames already normalised), texts = the oracle's ids
+        m = AuroraModel(eng, eos_token_id=eos)
+        ad = P.AuroraCapMI355X(pretrained="unused", device="cuda", batch_size=3, token_merge_ratio=0.5, _model=m, _tokenizer=FakeTok(),
+                               _preprocessor=lambda f: f)
+        ad._clip = lambda args: cs[args[3]]                                      # request doc_id -> (pixel_values, ids) of that clip
+        reqs = [SimpleNamespace(args=("ctx", {"max_new_tokens": N}, None, i, "t", "s")) for i in range(7)]
+        texts = ad.generate_until(reqs)
+        for i, (ids, lg) in enumerate(want):
+            toks = [int(x) for x in texts[i].split()]
+            assert_greedy_agrees_up_to_margin(toks, ids, lg)
+            if safe(ids, lg):
+                assert toks == ids, i
     finally:
         eng.close()

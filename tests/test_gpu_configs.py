@@ -159,7 +159,8 @@ def test_full_depth_cfg2_and_cfg3_batch_invariance_and_repeatability():
         eng.close()
 
 
-def test_vit_h_full_depth_every_layer_teacher_forced():
+@pytest.mark.parametrize("norm_std,bias_std", [(0.0, 0.0), (0.1, 0.05)])
+def test_vit_h_full_depth_every_layer_teacher_forced(norm_std, bias_std):
     """The complete vision tower at its real size (ViT-H/14-378, all 31 evaluated layers, r = 15: 730 -> 265 tokens) for one
     frame.  Run end to end, fp16 and fp32 arithmetic pick different merge pairs at some near tie within 31 steps and the
     token sets drift apart (measured: 6.5 % on the mean feature), so every layer is checked on ITS OWN input
@@ -168,7 +169,7 @@ def test_vit_h_full_depth_every_layer_teacher_forced():
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine
     v = S.AURORACAP_7B["vit"]
-    wg = S.vit_weights(v)
+    wg = S.vit_weights(v, norm_std=norm_std, bias_std=bias_std)      # (0.1, 0.05): LayerNorm weights / every bias away from 1 / 0
     f32 = lambda d: {k: ([f32(x) for x in val] if isinstance(val, list) else val.float().cpu()) for k, val in d.items()}
     w = f32(wg)
     eng = AuroraCapEngine({"vit": v, "llm": None}, {"vit": wg}, max_frames=1, max_batch=1, max_ctx=128, max_new_tokens=8)
@@ -193,7 +194,8 @@ def test_vit_h_full_depth_every_layer_teacher_forced():
         eng.close()
 
 
-def test_llama_7b_full_depth_teacher_forced_logits():
+@pytest.mark.parametrize("norm_std", [0.0, 0.1])
+def test_llama_7b_full_depth_teacher_forced_logits(norm_std):
     """Vicuna/Llama-7B at its real size (32 layers x d 4096 x MLP 11008, vocab 32000, linear RoPE scaling 4) with the seeded
     synthetic weights: a 96-token prefix + 5 greedy tokens; the CPU oracle replays the GPU's own tokens in one fp32 pass
     (teacher forcing) and its logits must match at every generated position within the tolerance of the small-model
@@ -202,7 +204,9 @@ def test_llama_7b_full_depth_teacher_forced_logits():
     from aurora_amd.engine import AuroraCapEngine
     from tests.test_gpu_llm import LOGIT_TOL, padded, teacher_forced_logits
     cfg = S.VICUNA_7B_16K
-    wg = S.llm_weights(cfg)
+    # norm_std 0.1: RMSNorm weights 1 + N(0, 0.1^2) - the FOLDED-norm decode path (W' = W diag(w_norm), rounded to fp16 at pack
+    # time) at full depth with weights as far from 1 as a real checkpoint's
+    wg = S.llm_weights(cfg, norm_std=norm_std)
     eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": wg}, max_frames=1, max_batch=1, max_ctx=256, max_new_tokens=8)
     try:
         emb = (torch.randn(96, 4096, generator=torch.Generator().manual_seed(4)) * 0.02).half().float()

@@ -37,6 +37,21 @@ def padded(emb):
     return out
 
 
+def assert_greedy_agrees_up_to_margin(got, ref_ids, ref_logits, tol=LOGIT_TOL):
+    """The margin rule of this suite for free-running greedy decodes: tokens must equal the oracle's at every position up to
+    the first one where the oracle's own top-1 / top-2 margin is inside twice the logit tolerance (past a legitimate flip the
+    two sequences condition on different tokens and are no longer comparable).  Returns the number of positions checked."""
+    scale = ref_logits.abs().max().item()
+    checked = 0
+    for i, (a, b) in enumerate(zip(got, ref_ids)):
+        top2 = ref_logits[i].topk(2).values
+        if (top2[0] - top2[1]).item() <= 2 * tol * scale:
+            break
+        assert a == b, (i, a, b, (top2[0] - top2[1]).item(), scale)
+        checked += 1
+    return checked
+
+
 def teacher_forced_logits(emb, ids, w, cfg):
     """Oracle logits at every generated position given the GPU's own tokens."""
     full = torch.cat([emb, w["embed_tokens.weight"][torch.tensor(ids[:-1], dtype=torch.long)]], 0) if len(ids) > 1 else emb
@@ -153,13 +168,8 @@ def test_projector_splice_and_whole_path():
         # whole path, greedy ids vs oracle (fp16-storage emulation), up to the first inside-tolerance margin
         out = eng.caption_ids(px, ids, 0.5, 12, eos_id=None)
         assert len(out) == 12
-        ref = O.caption_ids(px, ids, w, {"vit": vcfg, "llm": lcfg}, 0.5, 12, eos_id=None, q=O.fp16_storage)
-        agree = 0
-        for a, b in zip(out, ref):
-            if a != b:
-                break
-            agree += 1
-        assert agree >= 1
+        ref, ref_logits = O.caption_ids(px, ids, w, {"vit": vcfg, "llm": lcfg}, 0.5, 12, eos_id=None, q=O.fp16_storage, return_logits=True)
+        assert_greedy_agrees_up_to_margin(out, ref, ref_logits)
     finally:
         eng.close()
 

@@ -66,8 +66,8 @@ def test_vicuna_v1_prompt_and_image_tokens():
     assert P.question_with_image_tokens("<image>\nalready there", 3) == "<image>\nalready there"
     assert P.question_with_image_tokens("no visuals", 0) == "no visuals"
     p = P.conv_prompt(q)
-    assert p == ("A chat between a curious human and an artificial intelligence assistant. The assistant gives helpful, "
-                 "detailed, and polite answers to the human's questions. USER: <image> <image> <image>\n"
+    assert p == ("A chat between a curious user and an artificial intelligence assistant. The assistant gives helpful, "
+                 "detailed, and polite answers to the user's questions. USER: <image> <image> <image>\n"
                  "Describe the video in detail. ASSISTANT:")
     with pytest.raises(NotImplementedError):
         P.conv_prompt(q, "llava_llama_3")
@@ -212,3 +212,30 @@ def test_engine_device_normalisation(monkeypatch):
     assert AuroraCapEngine.normalize_device("cuda:1") == torch.device("cuda", 1)
     with pytest.raises(AuroraHipError):
         AuroraCapEngine.normalize_device("cpu")
+
+
+def test_g12_prompts_and_ids_of_the_reference_adaptor_helpers():
+    """tests/golden/g12_adaptor_prompts.npz: prompt strings from the reference's own vendored
+    llava.conversation.conv_templates["vicuna_v1"] and ids from its llava.mm_utils.tokenizer_image_token
+    (lmms_eval/models/auroracap.py:445-449, 478), generated by tests/golden/make_golden_adaptor.py in the build container.
+    The restated helpers of the MI355X adaptor must reproduce every one of them exactly."""
+    import json
+    from tests.util import golden
+    g = golden("g12_adaptor_prompts.npz")
+    assert int(g["image_token_index"]) == P.IMAGE_TOKEN_INDEX and str(g["default_image_token"]) == P.DEFAULT_IMAGE_TOKEN
+
+    class CharTok:                                        # the fixture's tokenizer rule: ids = [1 if bos] + [10 + ord(c) % 50]
+        bos_token_id = 1
+
+        def __init__(self, add_bos):
+            self.add_bos = add_bos
+
+        def __call__(self, s):
+            return SimpleNamespace(input_ids=([1] if self.add_bos else []) + [10 + (ord(c) % 50) for c in s])
+    cases = json.loads(str(g["cases"]))
+    assert len(cases) == 6
+    for i, (context, n_img) in enumerate(cases):
+        prompt = P.conv_prompt(P.question_with_image_tokens(context, n_img))
+        assert prompt == str(g[f"prompt{i}"]), i
+        for tag, tok in (("bos", CharTok(True)), ("nobos", CharTok(False))):
+            assert P.tokenizer_image_token(prompt, tok) == g[f"ids{i}_{tag}"].tolist(), (i, tag)

@@ -66,6 +66,10 @@ def main():
     for variant, tag in ((0, "decode x-per-wave"), (1, "decode x-through-LDS")):
         eng.set_option("skinny_variant", variant)
         run(tag, dec)
+    eng.set_option("skinny_variant", 1)
+    eng.set_option("skinny_qkv_depth", 2)
+    run("x-through-LDS qkv depth 2", ["dec_qkv"])
+    eng.set_option("skinny_qkv_depth", 4)
     eng.set_option("skinny_variant", 1 if B > 32 else 0)
     if not args.quick:
         for nw in (4, 8):
