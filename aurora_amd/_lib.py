@@ -65,6 +65,7 @@ SIGNATURES = {
     "aur_slot_reset": (C.c_int, [_P, _I, _P]),
     "aur_slot_retire": (C.c_int, [_P, _I, _P]),
     "aur_slot_state": (C.c_int, [_P, _IP, _IP, _P]),
+    "aur_slot_collect": (C.c_int, [_P, _I, _I, _P, _P, _P]),
     "aur_tome_step": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aur_linear": (C.c_int, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "aur_linear_skinny": (C.c_int, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),

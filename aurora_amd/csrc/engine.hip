@@ -1027,6 +1027,14 @@ extern "C" int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finishe
     CK(hipStreamSynchronize(s));
     return AUR_OK;
 }
+extern "C" int aur_slot_collect(aur_ctx* ctx, int32_t slot0, int32_t nslots, int32_t* ids_dev, int32_t* lens_dev, void* stream) {
+    if (int rc = slot_check(ctx, slot0, "aur_slot_collect")) return rc;
+    if (nslots < 1 || slot0 + nslots > ctx->batch || !ids_dev || !lens_dev) return aur_fail(ctx, AUR_ERR_ARG, "aur_slot_collect: slots [%d, %d) outside the batch of %d", slot0, slot0 + nslots, ctx->batch);
+    hipStream_t s = (hipStream_t)stream;
+    CK(hipMemcpyAsync(ids_dev, ctx->s_ids + (int64_t)slot0 * ctx->max_new, (size_t)nslots * ctx->max_new * 4, hipMemcpyDeviceToDevice, s));
+    CK(hipMemcpyAsync(lens_dev, ctx->s_len + slot0, (size_t)nslots * 4, hipMemcpyDeviceToDevice, s));
+    return AUR_OK;
+}
 extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
     if (ctx->batch < 1 || !dst_dev) return aur_fail(ctx, AUR_ERR_STATE, "aur_copy_logits: no active batch");
     CK(hipMemcpyAsync(dst_dev, ctx->d_logits, (size_t)ctx->batch * ctx->cfg.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -469,6 +469,13 @@ class AuroraCapEngine:
     def slot_retire(self, slot: int):
         check(self.ctx, self.L.aur_slot_retire(self.ctx, slot, self._stream()), "aur_slot_retire")
 
+    def slot_collect(self, slot0: int, nslots: int, ids_dev: torch.Tensor, lens_dev: torch.Tensor):
+        """Async device copy of the ids / lengths of slots [slot0, slot0 + nslots) (no host synchronisation)."""
+        assert ids_dev.dtype == torch.int32 and lens_dev.dtype == torch.int32 and ids_dev.is_contiguous() and lens_dev.is_contiguous()
+        assert ids_dev.numel() >= nslots * self._max_new and lens_dev.numel() >= nslots
+        check(self.ctx, self.L.aur_slot_collect(self.ctx, slot0, nslots, ids_dev.data_ptr(), lens_dev.data_ptr(), self._stream()),
+              "aur_slot_collect")
+
     def slot_state(self):
         lens = np.zeros(self._batch, np.int32)
         fin = np.zeros(self._batch, np.int32)

@@ -57,6 +57,7 @@ def parse():
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
     p.add_argument("--decode-chunk", type=int, default=0,
                    help="synchronise every N decode steps (rocprofv3 --kernel-trace segfaults with > ~150 hipGraph launches queued)")
+    p.add_argument("--no-latency-point", action="store_true", help="skip the steady-state continuous-batching pass (latency operating point)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
     return p.parse_args()
 
@@ -437,6 +438,71 @@ def main():
             torch.cuda.synchronize()
             lat.append(e0.elapsed_time(e1))
         result["ttft_ms_single_clip"] = float(np.median(lat))
+
+    # ---- latency operating point (rank 0, after the timed region): the SAME work as a steady-state serving loop.  All B KV
+    #      slots decode all the time; the slots are split into B / G groups whose captions end G-clip-group by group, evenly
+    #      spaced over the N - 1 decode steps of a caption; a finished group is collected on the device (aur_slot_collect, no
+    #      host sync), reset, and re-filled with its next G clips (ViT + splice + one prefill pass of G sequences) between two
+    #      decode chunks.  Throughput stays that of the full decode batch while a clip's first token waits for ITS group's front
+    #      end only, not for the other B - G clips'.
+    if rank == 0 and not args.no_latency_point and not pipe and B % G == 0 and B // G >= 2 and N >= 2 * (B // G):
+        torch.cuda.synchronize()
+        NG, S = B // G, N - 1                                      # groups; decode steps per caption after its prefill
+        offs = [g * S // NG for g in range(NG)]                    # refill instants of the groups inside a cycle of S steps
+        ids_out = torch.zeros(NG, G, N, dtype=torch.int32, device=dev)
+        len_out = torch.zeros(NG, G, dtype=torch.int32, device=dev)
+        eng.select_bank(0)
+        eng.begin_batch(B, N, None)
+        for sl in range(B):
+            eng.slot_retire(sl)                                    # empty slots: finished, positions frozen
+        lat_ev = []
+
+        def refill(g, collect, timed):
+            if collect:
+                eng.slot_collect(g * G, G, ids_out[g], len_out[g])
+            for sl in range(g * G, (g + 1) * G):
+                eng.slot_reset(sl)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
+            for j in range(G):
+                eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+            eng.prefill_batch(g * G, G, emb_all, L0)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            if timed:
+                lat_ev.append((e0, e1))
+
+        def cycle(first, timed):
+            """S decode steps; group g is (re)filled before step offs[g]."""
+            for g in range(NG):
+                refill(g, collect=not first, timed=timed)
+                nxt = offs[g + 1] if g + 1 < NG else S
+                eng.decode(nxt - offs[g])
+
+        cycle(True, False)                                         # fill: the groups enter one after another
+        cycles = max(1, min(args.steps, 2))
+        fence_ev0 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t_lp = time.perf_counter()
+        for _ in range(cycles):
+            cycle(False, True)
+        torch.cuda.synchronize()
+        t_lp = time.perf_counter() - t_lp
+        # drain: one more cycle's worth of collects would need more decode; instead check what the LAST timed cycle collected -
+        # every group's ids must be the captions of the batch-mode steps (same clips, same slots: batch-invariant kernels)
+        got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
+        ok = all(got_len[g, j] == N and got_ids[g, j].tolist() == outs[0][g * G + j] for g in range(NG) for j in range(G)) if cycles >= 1 else True
+        assert ok, "steady-state continuous batching produced different captions than the batch-mode steps"
+        fe = [a.elapsed_time(b) for a, b in lat_ev]
+        result["latency_point"] = {
+            "mode": "steady-state continuous batching: %d KV slots always decoding, groups of %d clips re-filled every %d decode steps" % (B, G, S // NG),
+            "captions_per_s": B * cycles / t_lp, "frac_of_value": (B * cycles / t_lp) / value,
+            "p50_ttft_ms": float(np.median(fe)), "max_ttft_ms": float(np.max(fe)), "cycles_timed": cycles,
+            "ttft_note": "device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d "
+                         "clips) to its first tokens; the group enters between two decode chunks, so a request that arrives just after a "
+                         "chunk was enqueued additionally waits for that chunk (<= %d decode steps here; a server would enqueue shorter chunks)" % (G, S // NG + 1),
+            "verified": "ids of all %d clips equal the batch-mode steps'" % B}
     eng.close()
     del eng
     torch.cuda.empty_cache()

@@ -138,6 +138,10 @@ int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream);
 int aur_slot_reset(aur_ctx* ctx, int32_t slot, void* stream);
 int aur_slot_retire(aur_ctx* ctx, int32_t slot, void* stream);
 int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, void* stream);
+/* Asynchronous (no host synchronisation) device-to-device copy of the results of slots [slot0, slot0 + nslots): ids_dev int32
+ * [nslots, max_new_tokens], lens_dev int32 [nslots] - lets a serving loop collect finished captions and re-fill their slots
+ * without ever draining the stream (bench.py's steady-state latency point). */
+int aur_slot_collect(aur_ctx* ctx, int32_t slot0, int32_t nslots, int32_t* ids_dev, int32_t* lens_dev, void* stream);
 
 /* ---- kernel-level entry points (parity tests, reuse by other callers) --------------------------- */
 /* One ToMe step on caller data: replaces bipartite_soft_matching + merge_wavg (tome.py:18-98,207-219;

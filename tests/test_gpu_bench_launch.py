@@ -73,3 +73,13 @@ def test_gpus_flag_must_agree_with_the_launcher():
                MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + TINY, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_latency_operating_point_is_reported_and_verified():
+    """Steady-state continuous batching pass (groups of --prefill-group clips re-filled between decode chunks): present in
+    the line, throughput comparable to the batch mode, and its captions verified against the batch-mode steps."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--prefill-group", "2"] + TINY, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lp = _json_line(r.stdout)["latency_point"]
+    assert lp["captions_per_s"] > 0 and lp["p50_ttft_ms"] > 0 and "equal the batch-mode" in lp["verified"]

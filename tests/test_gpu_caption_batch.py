@@ -161,13 +161,14 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
     try:
         got = dict(eng.caption_stream(cs, 0.5, N, eos_id=eos, check_every=4))
         assert sorted(got) == list(range(7))
-        n_exact = 0
+        checked = 0
         for i, (ids, lg) in enumerate(want):
-            assert_greedy_agrees_up_to_margin(got[i], ids, lg)
+            checked += assert_greedy_agrees_up_to_margin(got[i], ids, lg)
             if safe(ids, lg):
                 assert got[i] == ids, i                                          # same tokens AND the same stopping point
-                n_exact += 1
-        assert n_exact >= 3, n_exact
+        # a random 320-word model keeps ~half of its margins inside the tolerance: require a meaningful number of compared
+        # positions over the 7 clips rather than whole captions
+        assert checked >= 10, checked
         # the adaptor end to end: HIP input stage is bypassed (frames already normalised), texts = the oracle's ids
         m = AuroraModel(eng, eos_token_id=eos)
         ad = P.AuroraCapMI355X(pretrained="unused", device="cuda", batch_size=3, token_merge_ratio=0.5, _model=m, _tokenizer=FakeTok(),

@@ -1,0 +1,98 @@
+"""GPU: the checkpoint path at REAL size.  No AuroraCap checkpoint is reachable offline, so the test writes
+one in the reference's own on-disk format (aurora.py:312-362 `to_xtuner_llava`, read back at inference.py:42-57):
+
+    <root>/                 HF Llama: config.json + SHARDED *.safetensors (model-0000k-of-0000n, like the 7B release)
+    <root>/visual_encoder/  HF CLIP vision tower: keys vision_model.*, plus the `pos_emb` alias (aurora.py:878 - the table the
+                            forward really uses; position_embedding.weight is deliberately scrambled here)
+    <root>/projector/       xtuner ProjectorModel: model.0.* / model.2.*
+
+with the seeded synthetic weights of the benchmark at full width and depth (ViT-H/14-378 32 layers, Llama-7B 32 layers) and
+norm weights / biases away from 1 / 0, loads it through AuroraModel.from_pretrained (config.json -> dims, shards -> fragment
+packing, folded RMSNorm weights) and requires the caption ids of a clip to be IDENTICAL to those of an engine built from the
+same tensors in memory.  ~15 GB of disk traffic: the slowest test of the suite (about two minutes)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def write_checkpoint(root, vcfg, lcfg, vw, pw, lw, shards=4):
+    from safetensors.torch import save_file
+    os.makedirs(os.path.join(root, "visual_encoder"))
+    os.makedirs(os.path.join(root, "projector"))
+    cpu = lambda t: t.detach().to("cpu").contiguous()
+    D = vcfg["hidden_size"]
+    vs = {"vision_model.embeddings.patch_embedding.weight": cpu(vw["patch_embedding.weight"]),
+          "vision_model.embeddings.class_embedding": cpu(vw["class_embedding"]),
+          # the reference's forward takes its table from `pos_emb` (aurora.py:878, 899); a loader that read the HF key would fail
+          "vision_model.embeddings.position_embedding.weight": cpu(vw["position_embedding.weight"]).flip(0),
+          "pos_emb": cpu(vw["position_embedding.weight"]),
+          "vision_model.pre_layrnorm.weight": cpu(vw["pre_layrnorm.weight"]), "vision_model.pre_layrnorm.bias": cpu(vw["pre_layrnorm.bias"]),
+          "vision_model.post_layernorm.weight": torch.ones(D, dtype=torch.float16), "vision_model.post_layernorm.bias": torch.zeros(D, dtype=torch.float16)}
+    for i, l in enumerate(vw["layers"]):
+        for k, t in l.items():
+            mod = "self_attn." if "proj" in k else ("mlp." if k.startswith("fc") else "")
+            vs[f"vision_model.encoder.layers.{i}.{mod}{k}"] = cpu(t)
+    save_file(vs, os.path.join(root, "visual_encoder", "model.safetensors"))
+    json.dump({"vision_config": dict(vcfg)}, open(os.path.join(root, "visual_encoder", "config.json"), "w"))
+    save_file({k: cpu(v) for k, v in pw.items()}, os.path.join(root, "projector", "model.safetensors"))
+    json.dump({"visual_hidden_size": D, "llm_hidden_size": lcfg["hidden_size"], "depth": 2, "hidden_act": "gelu"},
+              open(os.path.join(root, "projector", "config.json"), "w"))
+    # language model: layer-wise shards like the published 7B checkpoints
+    L = lcfg["num_hidden_layers"]
+    per = (L + shards - 1) // shards
+    for s in range(shards):
+        part = {}
+        if s == 0:
+            part["model.embed_tokens.weight"] = cpu(lw["embed_tokens.weight"])
+        if s == shards - 1:
+            part["model.norm.weight"] = cpu(lw["norm.weight"])
+            part["lm_head.weight"] = cpu(lw["lm_head.weight"])
+        for i in range(s * per, min(L, (s + 1) * per)):
+            for k, t in lw["layers"][i].items():
+                mod = "self_attn." if k[0] in "qkvo" and "proj" in k else ("mlp." if "proj" in k else "")
+                part[f"model.layers.{i}.{mod}{k}"] = cpu(t)
+        save_file(part, os.path.join(root, f"model-{s + 1:05d}-of-{shards:05d}.safetensors"))
+    json.dump(dict(architectures=["LlamaForCausalLM"], hidden_size=lcfg["hidden_size"], num_attention_heads=lcfg["num_attention_heads"],
+                   num_key_value_heads=lcfg["num_attention_heads"], num_hidden_layers=L, intermediate_size=lcfg["intermediate_size"],
+                   vocab_size=lcfg["vocab_size"], rms_norm_eps=lcfg["rms_norm_eps"], rope_theta=lcfg["rope_theta"],
+                   rope_scaling={"type": "linear", "factor": lcfg["rope_factor"]}, bos_token_id=1, eos_token_id=2),
+              open(os.path.join(root, "config.json"), "w"))
+
+
+def test_real_size_xtuner_checkpoint_through_from_pretrained(tmp_path):
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine
+    from aurora_amd.model import AuroraModel
+    free = os.statvfs(str(tmp_path))
+    if free.f_bavail * free.f_frsize < 24 * 2**30:
+        pytest.skip("needs 24 GB of scratch disk for the real-size checkpoint")
+    vcfg, lcfg = S.VIT_H_378, S.VICUNA_7B_16K
+    vw = S.vit_weights(vcfg, norm_std=0.1, bias_std=0.05)
+    pw = S.projector_weights(vcfg["hidden_size"], lcfg["hidden_size"])
+    lw = S.llm_weights(lcfg, norm_std=0.1)
+    root = str(tmp_path / "AuroraCap-7B-synthetic")
+    write_checkpoint(root, vcfg, lcfg, vw, pw, lw)
+    F, N = 2, 8
+    px = S.frames(F, 5)
+    ids = S.prompt_ids(F, 5)
+    kw = dict(max_frames=F, max_batch=1, max_ctx=2048, max_new_tokens=N)
+    eng = AuroraCapEngine({"vit": vcfg, "llm": lcfg}, {"vit": vw, "projector": pw, "llm": lw}, **kw)
+    try:
+        want = eng.caption_ids(px, ids, 0.3, N, eos_id=None)
+    finally:
+        eng.close()
+    del eng, vw, pw, lw
+    torch.cuda.empty_cache()
+    m = AuroraModel.from_pretrained(root, **kw)
+    try:
+        assert m.engine.v["num_hidden_layers"] == 32 and m.engine.l["rope_factor"] == 4.0 and m.llm.eos_token_id == 2
+        m.visual_encoder.reset_tome_r(0.3)
+        out = m({"pixel_values": px.unsqueeze(0), "input_ids": torch.tensor([ids])}, mode="inference")
+        got = m.llm.generate(**out, do_sample=False, num_beams=1, max_new_tokens=N, eos_token_id=None)[0].tolist()
+        assert got == want, (got, want)
+    finally:
+        m.engine.close()

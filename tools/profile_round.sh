@@ -1,0 +1,31 @@
+#!/bin/bash
+# Profiling passes of one round, run ON THE GPU BOX:   gpurun -- 'bash tools/profile_round.sh r02'
+#   1. rocprofv3 --kernel-trace --stats of one full default bench step (decode synchronised every 64 steps: the tracer
+#      segfaults with > ~150 graph launches queued);
+#   2. three SEPARATE --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA busy + GRBM_GUI_ACTIVE) of a short eager step (6 new tokens),
+#      each with --kernel-trace only (gpurun refuses --pmc together with the other trace domains).
+# Summaries land in gpurun_out/prof_<tag>/ and are copied to profiles/ by the builder.
+TAG=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline"
+for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside a kernel launch: retry
+  rm -rf "$OUT/trace"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 1 --warmup 0 --decode-chunk 64 --no-latency-point > "$OUT/trace.log" 2>&1 && break
+done
+python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
+python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
+SHORT="$BENCH --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --no-latency-point"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $SHORT > "$OUT/pmc_fetch.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $SHORT > "$OUT/pmc_write.log" 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- $SHORT > "$OUT/pmc_mfma.log" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT" "$OUT/${TAG}_pmc.json" > "$OUT/${TAG}_pmc_summary.txt" 2>&1
+# keep the merge-back under 64 MiB: drop the raw per-dispatch csv / db files, keep logs + summaries
+for f in $(find "$OUT" -name "*counter_collection.csv" | head -3); do head -3 "$f" > "$f.head.txt"; done
+find "$OUT" -name "*.csv" -size +2M -delete
+find "$OUT" -name "*.db" -delete
+ls -la "$OUT"
+tail -3 "$OUT/trace.log"
+head -50 "$OUT/${TAG}_pmc_summary.txt"
