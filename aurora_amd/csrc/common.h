@@ -49,9 +49,12 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(k x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction IEEE division: these run 128 times
+// per lane in the epilogue of every 256x256 MLP tile (measured 6.8 us of a 40 us ViT fc1 tile with the IEEE form); the outputs are
+// rounded to fp16 right after, 13 bits above the difference.
+__device__ __forceinline__ float quick_gelu_f(float x) { return __fdividef(x, 1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
 
 // PAIRED k-slot helpers: position of element k (0..31) inside a fragment lane group.
 __device__ __host__ __forceinline__ int paired_g(int k) { return (k & 15) >> 2; }

@@ -14,6 +14,12 @@
 //    flight across the K-tile boundary), and every slot is re-filled >= 2 barriers after its last ds_read.
 //      RAW: the wait sits before phase 3's first barrier, the first read of the new tile is two barriers later
 //           (one for the staggered group).  WAR: see the table in DESIGN.md section 4.
+//  * PERSISTENT workgroups (one per CU) walk the output tiles, and the NEXT tile's prologue (its first 7 half-tiles of LDS-DMA)
+//    is issued before the CURRENT tile's epilogue: a 256x256 tile costs ~20 us on top of its K loop when every tile is its own
+//    workgroup (dispatch + cold prologue round trip + store drain, one workgroup per CU because of the 160 KiB of LDS; measured
+//    with a K sweep: 23 us at K = 128, +1.45 us per 64 of K - tools/gemm_probe.py), i.e. 40 % of a ViT tile (K = 1280) and 18 %
+//    of a prefill tile (K = 4096).  With the overlap only the store drain (vmcnt(0) before the next tile's first barrier) is
+//    left exposed.  LDS is free for the next prologue as soon as the K loop's last, group-aligning barrier has been passed.
 #include "gemm_epilogue.h"
 
 #define G2_LDS (160 * 1024)
@@ -32,16 +38,14 @@
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
-template <int EPI, bool VMODE>
-__device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&acc)[4][8], int bm, int bn, int w, int lane) {
-    const int wr = w >> 2, wc = w & 3;
-    const int r = lane & 15, g = lane >> 4;
-    const int K32 = a.K >> 5, nkt = a.K >> 6;
+// per-thread LDS-DMA sources of one output tile: 2 instructions per half-tile
+struct G2Src {
+    const half_t* a[2][2];
+    const half_t* w[2][2];
+};
+__device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, int w, int lane, G2Src& src) {
+    const int K32 = a.K >> 5;
     const int m0 = bm * 256;
-
-    // per-thread LDS-DMA sources: 2 instructions per half-tile
-    const half_t* a_src[2][2];
-    const half_t* w_src[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -51,20 +55,44 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             int m = m0 + h * 128 + row;
             m = m < a.M ? m : a.M - 1;
-            a_src[h][i] = a.A + (int64_t)m * a.lda + c * 8;
+            src.a[h][i] = a.A + (int64_t)m * a.lda + c * 8;
             const int f = grp;                      // fragment of the half-tile: n16 = f >> 1, kk = f & 1
-            w_src[h][i] = a.W + ((int64_t)(bn * 16 + h * 8 + (f >> 1)) * K32 + (f & 1)) * AUR_FRAG_HALVES + lane * 8;
+            src.w[h][i] = a.W + ((int64_t)(bn * 16 + h * 8 + (f >> 1)) * K32 + (f & 1)) * AUR_FRAG_HALVES + lane * 8;
         }
-    auto stage_a = [&](int h, int kt) {
-        char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
-        glds16(a_src[h][0] + kt * 64, dst + (w * 2 + 0) * 1024);
-        glds16(a_src[h][1] + kt * 64, dst + (w * 2 + 1) * 1024);
-    };
-    auto stage_w = [&](int h, int kt, int wb) {        // wb = kt % 3
-        char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
-        glds16(w_src[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
-        glds16(w_src[h][1] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 1) * 1024);
-    };
+}
+__device__ __forceinline__ void g2_stage_a(const G2Src& src, char* smem, int w, int h, int kt) {
+    char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
+    glds16(src.a[h][0] + kt * 64, dst + (w * 2 + 0) * 1024);
+    glds16(src.a[h][1] + kt * 64, dst + (w * 2 + 1) * 1024);
+}
+__device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, int h, int kt, int wb) {       // wb = kt % 3
+    char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
+    glds16(src.w[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
+    glds16(src.w[h][1] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 1) * 1024);
+}
+// prologue of a tile: K-tile 0 completely (8 instructions), plus W0, W1, A0 of K-tile 1 (6 instructions that may stay in flight)
+__device__ __forceinline__ void g2_prologue(const GemmArgs& a, const G2Src& src, char* smem, int w) {
+    g2_stage_a(src, smem, w, 0, 0);
+    g2_stage_a(src, smem, w, 1, 0);
+    g2_stage_w(src, smem, w, 0, 0, 0);
+    g2_stage_w(src, smem, w, 1, 0, 0);
+    if ((a.K >> 6) > 1) {
+        g2_stage_w(src, smem, w, 0, 1, 1);
+        g2_stage_w(src, smem, w, 1, 1, 1);
+        g2_stage_a(src, smem, w, 0, 1);
+    }
+}
+
+// K loop of one tile.  On entry the tile's prologue has been ISSUED (g2_prologue); `first` = nothing else is in flight, so the
+// counted wait of the original prologue applies; otherwise the previous tile's epilogue stores are in flight behind the DMAs and
+// the wait drains everything (stores and loads share vmcnt).
+template <int EPI, bool VMODE>
+__device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src, char* smem, f4 (&acc)[4][8], int w, int lane, bool first) {
+    const int wr = w >> 2, wc = w & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int nkt = a.K >> 6;
+    auto stage_a = [&](int h, int kt) { g2_stage_a(src, smem, w, h, kt); };
+    auto stage_w = [&](int h, int kt, int wb) { g2_stage_w(src, smem, w, h, kt, wb); };
 
     // fragment read offsets inside a buffer
     const int sw = (r >> 1) & 7;
@@ -106,19 +134,9 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
         __builtin_amdgcn_s_setprio(0);                                                                       \
     } while (0)
 
-    // ---- prologue: K-tile 0 completely, plus W0, W1, A0 of K-tile 1 (stay in flight)
-    stage_a(0, 0);
-    stage_a(1, 0);
-    stage_w(0, 0, 0);
-    stage_w(1, 0, 0);
-    if (nkt > 1) {
-        stage_w(0, 1, 1);
-        stage_w(1, 1, 1);
-        stage_a(0, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // ---- the prologue was issued by the caller: K-tile 0 must have landed, W0, W1, A0 of K-tile 1 may stay in flight
+    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_BARRIER();
     if (wr == 1) G2_BARRIER();                    // stagger: waves 4-7 run one barrier behind
 
@@ -163,6 +181,89 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, char* smem, f4 (&
 #undef G2_COMPUTE
 }
 
+// EPI_ROW epilogue through LDS: full-line stores.
+// In the accumulator layout a lane owns 4 consecutive columns of one row per 16x16 tile, so the direct epilogue issues 32
+// 8-byte stores per lane whose wave-instructions each touch 16 rows x 32 B - store-ISSUE-bound (guide T21): measured 16-18 us per
+// 256x256 tile on top of a K loop of 1.6 us per 64 of K (tools/gemm_probe.py with the stores stubbed out: 4.6 us vs 22.6 us per tile
+// at K = 128, 33.7 vs 49.9 at K = 1280), i.e. a third of a ViT tile.  Here every wave transposes its 128 x 64 block through a
+// private 16-row fp32 slab in LDS (row stride 272 B: conflict-free ds_write_b128, 16-byte aligned ds_read_b128) and a lane then
+// owns 8 consecutive columns: ONE coalesced 16-byte residual load and ONE 16-byte store per lane, 8 rows x 128 B per
+// wave-instruction (16 instead of 32 store instructions, whole 128-byte lines).  Arithmetic is unchanged - bias, activation and
+// residual are added in fp32 in the same order before the single rounding to fp16 - so the result stays bit-identical to the
+// 128x128 kernel's epilogue.  The slabs live in the LDS the NEXT tile's prologue does not touch (weight buffer 2 and the second
+// half of activation buffer 1): the prologue's DMA is already in flight while this runs.
+#define G2_SLAB_STRIDE 272
+#define G2_SLAB_BYTES (16 * G2_SLAB_STRIDE)
+__device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem) {
+    const int r = lane & 15, g = lane >> 4;
+    char* slab = w < 6 ? smem + G2_WBASE + 2 * G2_WBUF + w * G2_SLAB_BYTES : smem + G2_ABUF + G2_SLOT + (w - 6) * G2_SLAB_BYTES;
+    f4 bias[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bias[t] = a.bias ? *(const f4*)(a.bias + nb + t * 16 + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+    const int row0 = lane >> 3, chunk = lane & 7;
+    const int n = nb + chunk * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[t][u][i] + bias[t][i];
+            if (a.act == ACT_QUICK_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
+            } else if (a.act == ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+            }
+            *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
+        }
+        asm volatile("" ::: "memory");                       // LDS writes above, reads below: same wave, program order
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row = hh * 8 + row0;
+            const int m = mb + u * 16 + row;
+            const f4 x0 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32);
+            const f4 x1 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16);
+            if (m >= a.M || n >= a.n_real) continue;
+            const int orow = a.out_rows ? a.out_rows[m] : m;
+            if (orow < 0) continue;
+            if (a.act == ACT_SILU_MUL) {                     // (gate, up) interleaved: 4 outputs at columns n / 2 .. n / 2 + 3
+                h4 o;
+                o[0] = (half_t)(silu_f(x0[0]) * x0[1]);
+                o[1] = (half_t)(silu_f(x0[2]) * x0[3]);
+                o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
+                o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
+                half_t* dst = a.C + (int64_t)orow * a.ldc + (n >> 1);
+                if (n + 8 <= a.n_real) *(h4*)dst = o;
+                else *(h2*)dst = h2{o[0], o[1]};             // n_real % 4 == 0: the chunk holds 4 real columns
+            } else {
+                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                const bool full = n + 8 <= a.n_real;
+                if (a.resid) {
+                    const half_t* rp = a.resid + (int64_t)m * a.ldr + n;
+                    if (full) {
+                        const h8 rr = *(const h8*)rp;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
+                    } else {
+                        const h4 rr = *(const h4*)rp;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+                    }
+                }
+                h8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
+                half_t* dst = a.C + (int64_t)orow * a.ldc + n;
+                if (full) *(h8*)dst = o;
+                else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,36 +273,57 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     const int nbn = a.Npad >> 8;
     const int nbm = (a.M + 255) >> 8;
     const int nwg = nbn * nbm;
-    // Persistent mode (gemm256_set_max_wgs): a fixed number of workgroups walks the tiles, so the GEMM occupies only that many
-    // CUs (one 160 KiB workgroup per CU) and leaves the others to a concurrently running stream.  gridDim.x is a multiple of 8
-    // there, so a workgroup's tiles keep the XCD (bid % 8) the remap assumes.  Default: one workgroup per tile.
+    // tile of a block id: XCD-aware bijective remap (guide T1), then super-rows of 4 M-tiles, column-major inside: an XCD's 32
+    // consecutive tiles are 4 (M) x 8 (N), so every weight half-tile is fetched from HBM once and re-used from the XCD's L2 by 4
+    // workgroups, every activation tile by 8.  gridDim.x is a multiple of 8 whenever a workgroup walks more than one tile, so
+    // its tiles keep the XCD (bid % 8) the remap assumes.
+    auto tile_of = [&](int bid, int& bm, int& bn) {
+        const int xcd = bid & 7, q = nwg >> 3, rem8 = nwg & 7;
+        const int lid = (xcd < rem8 ? xcd * (q + 1) : rem8 * (q + 1) + (xcd - rem8) * q) + (bid >> 3);
+        const int sr = lid / (4 * nbn), rem = lid - sr * 4 * nbn;
+        const int rows = (nbm - 4 * sr) < 4 ? (nbm - 4 * sr) : 4;
+        bn = rem / rows;
+        bm = 4 * sr + rem % rows;
+    };
+    int bm, bn;
+    G2Src src;
+    tile_of(blockIdx.x, bm, bn);
+    g2_sources(a, bm, bn, w, lane, src);
+    g2_prologue(a, src, smem, w);
+    bool first = true;
     for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-    int lid;
-    {   // XCD-aware bijective remap (guide T1)
-        const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-        lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    }
-    // super-rows of 4 M-tiles, column-major inside: an XCD's 32 consecutive tiles are 4 (M) x 8 (N), so every weight
-    // half-tile is fetched from HBM once and re-used from the XCD's L2 by 4 workgroups, every activation tile by 8
-    const int sr = lid / (4 * nbn), rem = lid - sr * 4 * nbn;
-    const int rows = (nbm - 4 * sr) < 4 ? (nbm - 4 * sr) : 4;
-    const int bn = rem / rows, bm = 4 * sr + rem % rows;
-    f4 acc[4][8];
+        f4 acc[4][8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[t][u] = f4{0.f, 0.f, 0.f, 0.f};
-    const int nb = bn * 256 + (w & 3) * 64;
-    const int mb = bm * 256 + (w >> 2) * 128;
-    const bool vmode = (EPI == EPI_QKV) && (nb >= a.q_cols + a.k_cols);
-    if (vmode) g2_mainloop<EPI, true>(a, smem, acc, bm, bn, w, lane);
-    else g2_mainloop<EPI, false>(a, smem, acc, bm, bn, w, lane);
-    gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
-    __syncthreads();                              // the next tile's prologue refills LDS
+            for (int u = 0; u < 8; ++u) acc[t][u] = f4{0.f, 0.f, 0.f, 0.f};
+        const int nb = bn * 256 + (w & 3) * 64;
+        const int mb = bm * 256 + (w >> 2) * 128;
+        const bool vmode = (EPI == EPI_QKV) && (nb >= a.q_cols + a.k_cols);
+        if (vmode) g2_mainloop<EPI, true>(a, src, smem, acc, w, lane, first);
+        else g2_mainloop<EPI, false>(a, src, smem, acc, w, lane, first);
+        first = false;
+        // every wave is past the K loop's last barrier: all LDS reads of this tile are done -> start the next tile's loads now,
+        // they fly while this tile's epilogue converts and stores
+        const int nxt = bid + gridDim.x;
+        if (nxt < nwg) {
+            tile_of(nxt, bm, bn);
+            g2_sources(a, bm, bn, w, lane, src);
+            g2_prologue(a, src, smem, w);
+        }
+        // 16-byte row accesses need 8-column alignment of every row (ldc, ldr multiples of 8 halves; SiLU*up writes n / 2: ldc % 4)
+        const bool wide = EPI == EPI_ROW && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
+        if (wide) g2_epilogue_row(a, acc, mb, nb, lane, w, smem);
+        else gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
     }
 }
 
+static int g_gemm256_cus = 256;
+
 hipError_t gemm256_init() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
+        g_gemm256_cus = cus;
     hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
@@ -219,7 +341,8 @@ void gemm256_set_max_wgs(int n) { g_gemm256_max_wgs = n > 0 ? (n + 7) & ~7 : 0; 
 
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     int ntiles = (a.Npad >> 8) * ((a.M + 255) >> 8);
-    if (g_gemm256_max_wgs > 0 && ntiles > g_gemm256_max_wgs) ntiles = g_gemm256_max_wgs;
+    const int cap = g_gemm256_max_wgs > 0 ? g_gemm256_max_wgs : (g_gemm256_cus & ~7);     // one 160 KiB workgroup per CU
+    if (ntiles > cap) ntiles = cap;
     dim3 grid(ntiles), block(512);
     if (epi == EPI_ROW) hipLaunchKernelGGL(gemm256_kernel<EPI_ROW>, grid, block, G2_LDS, s, a);
     else hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, grid, block, G2_LDS, s, a);

@@ -57,7 +57,10 @@ def parse():
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
     p.add_argument("--decode-chunk", type=int, default=0,
                    help="synchronise every N decode steps (rocprofv3 --kernel-trace segfaults with > ~150 hipGraph launches queued)")
-    p.add_argument("--no-latency-point", action="store_true", help="skip the steady-state continuous-batching pass (latency operating point)")
+    p.add_argument("--batch-mode", action="store_true",
+                   help="time K independent batches (front end of all B clips, then B-wide decode) instead of the default steady-state "
+                        "continuous batching (same work per step, first tokens ~5x later)")
+    p.add_argument("--no-latency-point", action="store_true", help="(kept for old command lines; the continuous mode is the default now)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
     return p.parse_args()
 
@@ -287,13 +290,82 @@ def main():
         torch.cuda.synchronize()
 
     out = None
-    if not pipe:
-        def step(record_ttft=False):
-            ev0, evs = front(0, record_ttft)
-            o = back(0)
-            if record_ttft:
-                ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+    NG, S = (B // G if B % G == 0 else 0), N - 1                   # groups of G slots; decode steps per caption after its prefill
+    continuous = not (args.batch_mode or pipe or args.decode_chunk > 0) and NG >= 2 and N >= 2 * NG
+    batch_ref = None
+
+    def step(record_ttft=False):
+        ev0, evs = front(0, record_ttft)
+        o = back(0)
+        if record_ttft:
+            ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
+        return o
+
+    if continuous:
+        # ---- steady-state continuous batching: all B KV slots decode all the time; the slots form B / G groups whose captions
+        #      end group by group, evenly spaced over the N - 1 decode steps of a caption.  A finished group is collected on the
+        #      device (aur_slot_collect: no host sync), reset and re-filled with its next G clips (ViT + splice + ONE prefill pass
+        #      of G sequences) between two decode chunks.  One "step" = one cycle of N - 1 decode steps = B captions completed
+        #      and B front ends run: exactly the work of one batch-mode step, but a clip's first token waits for its own
+        #      group's front end only.  (What the reference harness does one clip at a time, evaluator.py:406-411.)
+        t_b = time.perf_counter()
+        batch_ref = step(True)                                     # one batch-mode step: reference captions + its timing
+        torch.cuda.synchronize()
+        batch_ms, batch_ttft = 1e3 * (time.perf_counter() - t_b), float(np.median(ttft_ms))
+        ttft_ms.clear()
+        offs = [g * S // NG for g in range(NG)]                    # refill instants of the groups inside a cycle of S steps
+        ids_out = torch.zeros(NG, G, N, dtype=torch.int32, device=dev)
+        len_out = torch.zeros(NG, G, dtype=torch.int32, device=dev)
+        eng.select_bank(0)
+        eng.begin_batch(B, N, None)
+        for sl in range(B):
+            eng.slot_retire(sl)                                    # empty slots: finished, positions frozen
+        lat_ev = []
+
+        def refill(g, collect, timed):
+            if collect:
+                eng.slot_collect(g * G, G, ids_out[g], len_out[g])
+            for sl in range(g * G, (g + 1) * G):
+                eng.slot_reset(sl)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
+            for j in range(G):
+                eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+            eng.prefill_batch(g * G, G, emb_all, L0)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            if timed:
+                lat_ev.append((e0, e1))
+
+        def cycle(fill, timed):
+            """S decode steps; group g is (re)filled before step offs[g].  Returns the captions collected in this cycle."""
+            for g in range(NG):
+                refill(g, collect=not fill, timed=timed)
+                eng.decode((offs[g + 1] if g + 1 < NG else S) - offs[g])
+            if fill:
+                return None
+            got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()         # synchronises: the cycle has run
+            o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
+            if world > 1:
+                parallel.gather_results(o, N, B, cdev)             # RCCL all_gather over xGMI, once per cycle
             return o
+
+        cycle(True, False)                                         # fill: the groups enter one after another (untimed set-up)
+        for _ in range(max(args.warmup - 1, 0)):
+            cycle(False, False)
+        fence()
+        t_start = time.perf_counter()
+        outs = []
+        for _ in range(args.steps):
+            out = cycle(False, True)
+            outs.append(out)
+        fence()
+        elapsed = time.perf_counter() - t_start
+        # same clips in the same slots as the batch-mode step: batch-invariant kernels must give the same ids, every cycle
+        assert all(o == batch_ref for o in outs), "continuous batching produced different captions than the batch-mode step"
+        ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
+    elif not pipe:
         for _ in range(args.warmup):
             step()
         fence()
@@ -368,12 +440,22 @@ def main():
                                     % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
                        "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
                        "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
-                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G, "vit_chunk": VC,
+                       "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G, "vit_chunk": G if continuous else VC,
+                       "mode": ("continuous batching, steady state: %d KV slots always decoding; groups of %d clips are collected and re-filled "
+                                "(ViT + splice + one prefill pass) every %d decode steps; one step = one cycle of %d decode steps = %d captions "
+                                "completed + %d front ends" % (B, G, S // NG, S, B, B)) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
-            "ttft_note": "time from the start of a batch's front end to each clip's first token, batch of %d clips (ViT in chunks of %d clips, "
-                         "prefill in groups of %d)" % (B, VC, G) + ("; the front end shares the GPU with the previous batch's decode" if pipe else ""),
+            "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "
+                           "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1))
+                          if continuous else
+                          "time from the start of a batch's front end to each clip's first token, batch of %d clips (ViT in chunks of %d clips, "
+                          "prefill in groups of %d)" % (B, VC, G) + ("; the front end shares the GPU with the previous batch's decode" if pipe else "")),
         }
+        if continuous:
+            result["batch_mode"] = {"captions_per_s": B / (batch_ms / 1e3), "ms_per_step": batch_ms, "p50_ttft_ms": batch_ttft,
+                                    "note": "one step of the non-continuous schedule (all %d front ends, then the %d-wide decode), same captions; "
+                                            "host-timed around a single step after warm kernels" % (B, B)}
 
     # ---- instrumented pass (rank 0, after the timed region, not pipelined): HIP events per stage and around the
     #      two HBM-bound decode kernels
@@ -439,70 +521,6 @@ def main():
             lat.append(e0.elapsed_time(e1))
         result["ttft_ms_single_clip"] = float(np.median(lat))
 
-    # ---- latency operating point (rank 0, after the timed region): the SAME work as a steady-state serving loop.  All B KV
-    #      slots decode all the time; the slots are split into B / G groups whose captions end G-clip-group by group, evenly
-    #      spaced over the N - 1 decode steps of a caption; a finished group is collected on the device (aur_slot_collect, no
-    #      host sync), reset, and re-filled with its next G clips (ViT + splice + one prefill pass of G sequences) between two
-    #      decode chunks.  Throughput stays that of the full decode batch while a clip's first token waits for ITS group's front
-    #      end only, not for the other B - G clips'.
-    if rank == 0 and not args.no_latency_point and not pipe and B % G == 0 and B // G >= 2 and N >= 2 * (B // G):
-        torch.cuda.synchronize()
-        NG, S = B // G, N - 1                                      # groups; decode steps per caption after its prefill
-        offs = [g * S // NG for g in range(NG)]                    # refill instants of the groups inside a cycle of S steps
-        ids_out = torch.zeros(NG, G, N, dtype=torch.int32, device=dev)
-        len_out = torch.zeros(NG, G, dtype=torch.int32, device=dev)
-        eng.select_bank(0)
-        eng.begin_batch(B, N, None)
-        for sl in range(B):
-            eng.slot_retire(sl)                                    # empty slots: finished, positions frozen
-        lat_ev = []
-
-        def refill(g, collect, timed):
-            if collect:
-                eng.slot_collect(g * G, G, ids_out[g], len_out[g])
-            for sl in range(g * G, (g + 1) * G):
-                eng.slot_reset(sl)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
-            for j in range(G):
-                eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
-            eng.prefill_batch(g * G, G, emb_all, L0)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            if timed:
-                lat_ev.append((e0, e1))
-
-        def cycle(first, timed):
-            """S decode steps; group g is (re)filled before step offs[g]."""
-            for g in range(NG):
-                refill(g, collect=not first, timed=timed)
-                nxt = offs[g + 1] if g + 1 < NG else S
-                eng.decode(nxt - offs[g])
-
-        cycle(True, False)                                         # fill: the groups enter one after another
-        cycles = max(1, min(args.steps, 2))
-        fence_ev0 = torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t_lp = time.perf_counter()
-        for _ in range(cycles):
-            cycle(False, True)
-        torch.cuda.synchronize()
-        t_lp = time.perf_counter() - t_lp
-        # drain: one more cycle's worth of collects would need more decode; instead check what the LAST timed cycle collected -
-        # every group's ids must be the captions of the batch-mode steps (same clips, same slots: batch-invariant kernels)
-        got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
-        ok = all(got_len[g, j] == N and got_ids[g, j].tolist() == outs[0][g * G + j] for g in range(NG) for j in range(G)) if cycles >= 1 else True
-        assert ok, "steady-state continuous batching produced different captions than the batch-mode steps"
-        fe = [a.elapsed_time(b) for a, b in lat_ev]
-        result["latency_point"] = {
-            "mode": "steady-state continuous batching: %d KV slots always decoding, groups of %d clips re-filled every %d decode steps" % (B, G, S // NG),
-            "captions_per_s": B * cycles / t_lp, "frac_of_value": (B * cycles / t_lp) / value,
-            "p50_ttft_ms": float(np.median(fe)), "max_ttft_ms": float(np.max(fe)), "cycles_timed": cycles,
-            "ttft_note": "device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d "
-                         "clips) to its first tokens; the group enters between two decode chunks, so a request that arrives just after a "
-                         "chunk was enqueued additionally waits for that chunk (<= %d decode steps here; a server would enqueue shorter chunks)" % (G, S // NG + 1),
-            "verified": "ids of all %d clips equal the batch-mode steps'" % B}
     eng.close()
     del eng
     torch.cuda.empty_cache()

@@ -43,7 +43,7 @@ def test_single_process_line_has_the_contract_fields():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
 
 
-@pytest.mark.parametrize("extra", [[], ["--pipeline"]])
+@pytest.mark.parametrize("extra", [[], ["--pipeline"], ["--prefill-group", "2"]])
 def test_two_ranks_torchrun_gloo(extra):
     env = dict(os.environ, AURORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -75,11 +75,17 @@ def test_gpus_flag_must_agree_with_the_launcher():
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
 
 
-def test_latency_operating_point_is_reported_and_verified():
-    """Steady-state continuous batching pass (groups of --prefill-group clips re-filled between decode chunks): present in
-    the line, throughput comparable to the batch mode, and its captions verified against the batch-mode steps."""
+def test_default_mode_is_steady_state_continuous_batching():
+    """With >= 2 prefill groups the timed region is the steady-state continuous-batching loop (groups of --prefill-group clips
+    collected and re-filled between decode chunks); its captions are verified inside bench.py against a batch-mode step, whose
+    timing is reported beside it."""
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--prefill-group", "2"] + TINY, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    lp = _json_line(r.stdout)["latency_point"]
-    assert lp["captions_per_s"] > 0 and lp["p50_ttft_ms"] > 0 and "equal the batch-mode" in lp["verified"]
+    d = _json_line(r.stdout)
+    assert d["config"]["mode"].startswith("continuous batching") and d["value"] > 0 and d["p50_ttft_ms"] > 0
+    assert d["batch_mode"]["captions_per_s"] > 0 and d["batch_mode"]["p50_ttft_ms"] > 0
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--prefill-group", "2", "--batch-mode"] + TINY, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and _json_line(r.stdout)["config"]["mode"].startswith("batch")

@@ -13,11 +13,11 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline"
 for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside a kernel launch: retry
   rm -rf "$OUT/trace"
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 1 --warmup 0 --decode-chunk 64 --no-latency-point > "$OUT/trace.log" 2>&1 && break
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 1 --warmup 0 --decode-chunk 64 > "$OUT/trace.log" 2>&1 && break
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
-SHORT="$BENCH --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --no-latency-point"
+SHORT="$BENCH --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --batch-mode"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $SHORT > "$OUT/pmc_fetch.log" 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $SHORT > "$OUT/pmc_write.log" 2>&1
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- $SHORT > "$OUT/pmc_mfma.log" 2>&1
