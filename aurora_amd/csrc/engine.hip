@@ -539,7 +539,7 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     GemmArgs q{};
     q.A = ctx->w_xn; q.lda = D; q.W = w.qkv_w; q.bias = w.qkv_b; q.M = M; q.Npad = ctx->v_qkv_npad; q.K = D;
     q.rows_per_seq = t_pad; q.q_cols = ctx->v_qcols; q.k_cols = ctx->v_qcols; q.hd = ctx->v_hd; q.Qf = ctx->w_qf;
-    q.kv = vit_kv(ctx, t_pad); q.rope = nullptr; q.pos0 = 0; q.seq0 = 0;
+    q.kv = vit_kv(ctx, t_pad); q.rope = nullptr; q.pos0 = 0; q.seq0 = 0; q.tag = GT_VIT_QKV;
     CK(launch_gemm(q, EPI_QKV, s));                                                        // aurora.py:634-636
     AttnArgs at{};
     at.Qf = ctx->w_qf; at.kv = q.kv; at.seq0 = 0; at.nseq = F; at.heads = g.vit_heads; at.rows_per_seq = t_pad; at.t = t;
@@ -547,7 +547,7 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     CK(launch_attention(at, s));                                                           // aurora.py:647-697
     GemmArgs o{};
     o.A = ctx->w_attn; o.lda = D; o.W = w.out_w; o.bias = w.out_b; o.M = M; o.Npad = ctx->v_dpad; o.K = D;
-    o.C = x; o.ldc = D; o.resid = x; o.ldr = D; o.n_real = D; o.act = ACT_NONE;
+    o.C = x; o.ldc = D; o.resid = x; o.ldr = D; o.n_real = D; o.act = ACT_NONE; o.tag = GT_VIT_OUT;
     CK(launch_gemm(o, EPI_ROW, s));                                                        // aurora.py:699, 743
     int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;                                            // tome.py:45
     half_t* xc = x;
@@ -569,11 +569,11 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     CK(launch_layernorm(xc, D, w.ln2_w, w.ln2_b, 1e-5f, M2, D, ctx->w_xn, D, s));         // aurora.py:750
     GemmArgs f1{};
     f1.A = ctx->w_xn; f1.lda = D; f1.W = w.fc1_w; f1.bias = w.fc1_b; f1.M = M2; f1.Npad = ctx->v_mlp_pad; f1.K = D;
-    f1.C = ctx->w_h; f1.ldc = g.vit_mlp; f1.n_real = g.vit_mlp; f1.act = g.vit_act == AUR_ACT_GELU ? ACT_GELU : ACT_QUICK_GELU;
+    f1.C = ctx->w_h; f1.ldc = g.vit_mlp; f1.n_real = g.vit_mlp; f1.act = g.vit_act == AUR_ACT_GELU ? ACT_GELU : ACT_QUICK_GELU; f1.tag = GT_VIT_FC1;
     CK(launch_gemm(f1, EPI_ROW, s));
     GemmArgs f2{};
     f2.A = ctx->w_h; f2.lda = g.vit_mlp; f2.W = w.fc2_w; f2.bias = w.fc2_b; f2.M = M2; f2.Npad = ctx->v_dpad; f2.K = g.vit_mlp;
-    f2.C = xc; f2.ldc = D; f2.resid = xc; f2.ldr = D; f2.n_real = D; f2.act = ACT_NONE;
+    f2.C = xc; f2.ldc = D; f2.resid = xc; f2.ldr = D; f2.n_real = D; f2.act = ACT_NONE; f2.tag = GT_VIT_FC2;
     CK(launch_gemm(f2, EPI_ROW, s));                                                       // aurora.py:751-752
     *x_res = xc;
     *size_res = sc;
@@ -821,7 +821,7 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
         GemmArgs q{};
         q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
         q.rows_per_seq = Mseq; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
-        q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot;
+        q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot; q.tag = GT_LLM_QKV;
         CK(launch_gemm(q, EPI_QKV, s));
     }
     if (which & 4) {
@@ -833,20 +833,20 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
     if (which & 8) {
         GemmArgs o{};
         o.A = ctx->l_attn; o.lda = d; o.W = w.o_w; o.M = M; o.Npad = ctx->l_dpad; o.K = d; o.C = x; o.ldc = d; o.resid = x; o.ldr = d;
-        o.n_real = d; o.act = ACT_NONE;
+        o.n_real = d; o.act = ACT_NONE; o.tag = GT_LLM_O;
         CK(launch_gemm(o, EPI_ROW, s));
     }
     if (which & 16) CK(launch_rmsnorm(x, d, nullptr, g.llm_rms_eps, M, d, ctx->l_xn, d, s));     // weight folded into gateup.w
     if (which & 32) {
         GemmArgs gu{};
         gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
-        gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL;
+        gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL; gu.tag = GT_LLM_GATEUP;
         CK(launch_gemm(gu, EPI_ROW, s));
     }
     if (which & 64) {
         GemmArgs dn{};
         dn.A = ctx->l_h; dn.lda = g.llm_mlp; dn.W = w.down_w; dn.M = M; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.C = x; dn.ldc = d;
-        dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE;
+        dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE; dn.tag = GT_LLM_DOWN;
         CK(launch_gemm(dn, EPI_ROW, s));
     }
     return AUR_OK;

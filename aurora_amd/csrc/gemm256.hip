@@ -264,7 +264,7 @@ __device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][
     }
 }
 
-template <int EPI>
+template <int EPI, int TAG>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -320,13 +320,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 
 static int g_gemm256_cus = 256;
 
+template <int EPI, int TAG>
+static hipError_t g2_attr() {
+    return hipFuncSetAttribute((const void*)gemm256_kernel<EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+}
 hipError_t gemm256_init() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
         g_gemm256_cus = cus;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    hipError_t e;
+    if ((e = g2_attr<EPI_ROW, GT_OTHER>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_VIT_OUT>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_VIT_FC1>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_VIT_FC2>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LLM_O>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LLM_GATEUP>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LLM_DOWN>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_OTHER>()) != hipSuccess ||
+        (e = g2_attr<EPI_QKV, GT_VIT_QKV>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_LLM_QKV>()) != hipSuccess)
+        return e;
+    return hipSuccess;
 }
 
 bool gemm256_eligible(const GemmArgs& a) {
@@ -344,7 +353,24 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     const int cap = g_gemm256_max_wgs > 0 ? g_gemm256_max_wgs : (g_gemm256_cus & ~7);     // one 160 KiB workgroup per CU
     if (ntiles > cap) ntiles = cap;
     dim3 grid(ntiles), block(512);
-    if (epi == EPI_ROW) hipLaunchKernelGGL(gemm256_kernel<EPI_ROW>, grid, block, G2_LDS, s, a);
-    else hipLaunchKernelGGL(gemm256_kernel<EPI_QKV>, grid, block, G2_LDS, s, a);
+#define G2_LAUNCH(E, T) hipLaunchKernelGGL((gemm256_kernel<E, T>), grid, block, G2_LDS, s, a)
+    if (epi == EPI_ROW) {
+        switch (a.tag) {
+            case GT_VIT_OUT: G2_LAUNCH(EPI_ROW, GT_VIT_OUT); break;
+            case GT_VIT_FC1: G2_LAUNCH(EPI_ROW, GT_VIT_FC1); break;
+            case GT_VIT_FC2: G2_LAUNCH(EPI_ROW, GT_VIT_FC2); break;
+            case GT_LLM_O: G2_LAUNCH(EPI_ROW, GT_LLM_O); break;
+            case GT_LLM_GATEUP: G2_LAUNCH(EPI_ROW, GT_LLM_GATEUP); break;
+            case GT_LLM_DOWN: G2_LAUNCH(EPI_ROW, GT_LLM_DOWN); break;
+            default: G2_LAUNCH(EPI_ROW, GT_OTHER); break;
+        }
+    } else {
+        switch (a.tag) {
+            case GT_VIT_QKV: G2_LAUNCH(EPI_QKV, GT_VIT_QKV); break;
+            case GT_LLM_QKV: G2_LAUNCH(EPI_QKV, GT_LLM_QKV); break;
+            default: G2_LAUNCH(EPI_QKV, GT_OTHER); break;
+        }
+    }
+#undef G2_LAUNCH
     return hipGetLastError();
 }

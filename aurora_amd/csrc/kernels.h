@@ -28,7 +28,11 @@ struct GemmArgs {
     const float2* rope;     // [pos][hd/2] (cos, sin) or nullptr
     int pos0;               // position of row 0 of each sequence (multiple of 32)
     int seq0;               // first sequence's row in the page table
+    int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
+                            // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
+                            // grid is the same for every shape) separate the shapes - profiles/*_kernel_stats.txt, *_pmc.json
 };
+enum { GT_OTHER = 0, GT_VIT_QKV, GT_VIT_OUT, GT_VIT_FC1, GT_VIT_FC2, GT_LLM_QKV, GT_LLM_O, GT_LLM_GATEUP, GT_LLM_DOWN, GT_COUNT };
 
 hipError_t gemm_init();
 hipError_t attn_init();

@@ -472,11 +472,18 @@ def main():
         result["stage_ms_instrumented_step"] = stages
         d, mlp = l["hidden_size"], l["intermediate_size"]
         how = "HIP events around every launch of this kernel in one extra eager, un-pipelined step on the launch stream (after the timed steps)"
-        pmc = {}
-        try:                                                       # rocprofv3 --pmc summary of this same command, if committed
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        # rocprofv3 --pmc summary of this same command (tools/profile_round.sh -> profiles/r02_pmc.json), if committed: per-kernel
+        # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE KiB, separate passes) measured at 6 new tokens, scaled to this run below
+        pmc, pmc_ctx = {}, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            pmc_ctx = pj.get("_batch_x_ctx")
+            for ent in pj["kernels"]:
+                if "hbm_bytes_per_launch" in ent:
+                    pmc.setdefault(ent["kernel"].split("(")[0].replace("void ", ""), ent)
         except Exception:
             pass
+        pmc_of = lambda needle: next((v for k, v in pmc.items() if needle in k), None)
         roof = {}
         if an > 0:
             # decode attention: K + V of every cached token of every sequence, all heads, read once per layer-step; the
@@ -486,18 +493,18 @@ def main():
             avg_s = ams / an * 1e-3
             roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_pipe_kernel<4, 8> (paged decode attention)",
                                    "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                   "traffic": (pmc["decode_attn_pipe_kernel"]["bytes_per_launch"] * (B * mean_ctx) /
-                                               (pmc["_batch"] * pmc["_ctx_tokens"])) if "decode_attn_pipe_kernel" in pmc else None,
-                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/pmc_traffic.json, "
-                                                   "scaled linearly from its batch x context to this run's",
+                                   "traffic": (pmc_of("decode_attn_pipe_kernel")["hbm_bytes_per_launch"] * (B * mean_ctx) / pmc_ctx)
+                                   if (pmc_of("decode_attn_pipe_kernel") and pmc_ctx) else None,
+                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/r02_pmc.json (separate passes of this "
+                                                   "command at 6 new tokens), scaled linearly from its batch x context to this run's",
                                    "algorithmic_bytes_per_launch": alg,
                                    "avg_launch_us": avg_s * 1e6, "launches_timed": an, "how": how}
         if kn > 0:
             alg = 2 * mlp * d * 2 + B * d * 2 + B * mlp * 2           # gate+up rows fp16 + x in + h out
             avg_s = kms / kn * 1e-3
-            roof["decode_gateup"] = {"bound": "hbm", "kernel": "skinny_kernel<2, SK_SILU_MUL> (decode gate/up projection)",
+            roof["decode_gateup"] = {"bound": "hbm", "kernel": "skinny_lds_kernel<6, 2, SK_SILU_MUL> (decode gate/up projection, x through LDS)",
                                      "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                     "traffic": pmc["skinny_kernel_gateup"]["bytes_per_launch"] if "skinny_kernel_gateup" in pmc else None,
+                                     "traffic": pmc_of("skinny_lds_kernel<6, 2, 2")["hbm_bytes_per_launch"] if pmc_of("skinny_lds_kernel<6, 2, 2") else None,
                                      "algorithmic_bytes_per_launch": alg,
                                      "avg_launch_us": avg_s * 1e6, "launches_timed": kn, "how": how}
         if roof:    # the dominant kernel = the one with the larger total time in the decode loop
@@ -506,6 +513,49 @@ def main():
             for k, val in roof.items():
                 if k != dom:
                     result["roofline_" + k] = val
+        # ---- MFMA-bound stages and the whole step against the roofline (SURVEY 8d work model; peaks: 8 TB/s, 2.5 PF dense fp16)
+        if not args.tiny:
+            Dv, mlpv, Lv = v["hidden_size"], v["intermediate_size"], v["num_hidden_layers"]
+            hdv = Dv // v["num_attention_heads"]
+            vit_fl = 2.0 * (t0tok - 1) * (3 * v["patch_size"] ** 2) * Dv
+            t = t0tok
+            for _ in range(Lv - 1):
+                rl = min(r, (t - 1) // 2)
+                vit_fl += 8.0 * t * Dv * Dv + 4.0 * t * t * Dv + 2.0 * ((t + 1) // 2) * (t // 2) * hdv + 4.0 * (t - rl) * Dv * mlpv
+                t -= rl
+            vit_fl *= F                                                                  # per clip
+            proj_fl = 2.0 * F * n_kept * (Dv * d + d * d)
+            per_tok = 2.0 * l["num_hidden_layers"] * (4 * d * d + 3 * d * mlp)
+            pre_fl = per_tok * L0 + 2.0 * l["num_hidden_layers"] * d * L0 * L0 + 2.0 * l["vocab_size"] * d
+            w_bytes = 2.0 * (l["num_hidden_layers"] * (4 * d * d + 3 * d * mlp) + l["vocab_size"] * d)
+            dec_bytes = (N - 1) * w_bytes + B * sum(2.0 * l["num_hidden_layers"] * d * 2 * (L0 + s_) for s_ in range(1, N))   # per batch of B
+            result["roofline_vit"] = {"bound": "mfma", "stage": "ViT-H + per-layer ToMe, %d clips (instrumented eager step)" % B,
+                                      "achieved": B * vit_fl / (stages["vit"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                      "frac": B * vit_fl / (stages["vit"] * 1e-3) / 2.5e15, "algorithmic_flops_per_clip": vit_fl, "traffic": None}
+            result["roofline_prefill"] = {"bound": "mfma", "stage": "Llama prefill of %d x %d tokens in groups of %d (instrumented eager step)" % (B, L0, G),
+                                          "achieved": B * pre_fl / (stages["prefill"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                          "frac": B * pre_fl / (stages["prefill"] * 1e-3) / 2.5e15, "algorithmic_flops_per_clip": pre_fl, "traffic": None}
+            try:                                                   # the prefill GEMMs alone, back to back (aur_microbench)
+                eng.set_option("microbench_prefill_nseq", G)
+                Mg = G * Mseq
+                shapes = {"pre_qkv": 3 * d * d, "pre_o": d * d, "pre_gateup": 2 * mlp * d, "pre_down": mlp * d}
+                us = {k: eng.microbench(k, 32) for k in shapes}
+                fl = {k: 2.0 * Mg * nk for k, nk in shapes.items()}
+                tot_fl, tot_us = sum(fl.values()), sum(us.values())
+                g_ent = pmc_of("gemm256_kernel<0, 7>")
+                result["roofline_prefill_gemm"] = {"bound": "mfma", "kernel": "gemm256_kernel (qkv, o, gate/up, down at M = %d)" % Mg,
+                                                   "achieved": tot_fl / tot_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s", "frac": tot_fl / tot_us / 2.5e9,
+                                                   "per_projection_tflops": {k: fl[k] / us[k] / 1e6 for k in shapes}, "avg_launch_us": us,
+                                                   "mfma_util_pmc": g_ent.get("mfma_util") if g_ent else None,
+                                                   "clock_ghz_pmc": g_ent.get("clock_ghz") if g_ent else None,
+                                                   "traffic": g_ent.get("hbm_bytes_per_launch") if g_ent else None,
+                                                   "how": "aur_microbench: 32 back-to-back launches per projection cycling through the layers (HIP events)"}
+            except Exception as ex:                                # the bench line must still print
+                result["roofline_prefill_gemm"] = {"error": repr(ex)}
+            ideal_s = dec_bytes / 8e12 + B * (pre_fl + vit_fl + proj_fl) / 2.5e15
+            result["roofline_step"] = {"ideal_ms": 1e3 * ideal_s, "measured_ms": result["ms_per_step"], "frac": 1e3 * ideal_s / result["ms_per_step"],
+                                       "model": "decode: weights once per step + K/V of every cached token, at 8 TB/s; ViT, projector and prefill "
+                                                "flops at 2.5 PFLOP/s (SURVEY 8d)"}
         # single-clip latency (batch 1): TTFT without queueing behind other clips' ViT/prefill
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -146,8 +146,9 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
     from tests.test_lmms_plugin import FakeTok
     cfg = {"vit": VCFG, "llm": LLM_CFGS["hd32"]}
     w = weights()
-    cs = clips(7, 21)
+    cs = clips(7, 7)             # seed chosen (CPU search over the oracle alone) for long runs of clear margins: 44 positions, one whole caption
     N = 14
+    TOL = 1e-2                   # tighter than the kernel-level 3e-2 bound: the drift of this tiny model is well below it
     free = [O.caption_ids(px.float(), ids, w, cfg, 0.5, N, eos_id=None, q=O.fp16_storage, return_logits=True) for px, ids in cs]
     eos = free[2][0][4]                                                          # occurs in clip 2's caption -> ragged stopping
     want = [(ids[: ids.index(eos) + 1] if eos in ids else ids, lg) for ids, lg in free]      # HF semantics: the EOS itself is emitted
@@ -155,7 +156,7 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
 
     def safe(ids, logits):                                                       # every margin clear of the tolerance?
         scale = logits.abs().max().item()
-        return all((logits[i].topk(2).values[0] - logits[i].topk(2).values[1]).item() > 2 * LOGIT_TOL * scale for i in range(len(ids)))
+        return all((logits[i].topk(2).values[0] - logits[i].topk(2).values[1]).item() > 2 * TOL * scale for i in range(len(ids)))
 
     eng = build(max_batch=3, max_new=N)
     try:
@@ -163,12 +164,10 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
         assert sorted(got) == list(range(7))
         checked = 0
         for i, (ids, lg) in enumerate(want):
-            checked += assert_greedy_agrees_up_to_margin(got[i], ids, lg)
+            checked += assert_greedy_agrees_up_to_margin(got[i], ids, lg, TOL)
             if safe(ids, lg):
                 assert got[i] == ids, i                                          # same tokens AND the same stopping point
-        # a random 320-word model keeps ~half of its margins inside the tolerance: require a meaningful number of compared
-        # positions over the 7 clips rather than whole captions
-        assert checked >= 10, checked
+        assert checked >= 30, checked                                           # positions really compared with the oracle
         # the adaptor end to end: HIP input stage is bypassed (frames already normalised), texts = the oracle's ids
         m = AuroraModel(eng, eos_token_id=eos)
         ad = P.AuroraCapMI355X(pretrained="unused", device="cuda", batch_size=3, token_merge_ratio=0.5, _model=m, _tokenizer=FakeTok(),
@@ -178,7 +177,7 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
         texts = ad.generate_until(reqs)
         for i, (ids, lg) in enumerate(want):
             toks = [int(x) for x in texts[i].split()]
-            assert_greedy_agrees_up_to_margin(toks, ids, lg)
+            assert_greedy_agrees_up_to_margin(toks, ids, lg, TOL)
             if safe(ids, lg):
                 assert toks == ids, i
     finally:

@@ -65,13 +65,14 @@ def read_pass(d):
 
 def main():
     root, out = sys.argv[1], sys.argv[2]
+    batch_x_ctx = float(sys.argv[3]) if len(sys.argv) > 3 else 64 * 2145.0     # decode attention: sequences x mean cached tokens of the pass
     F, W, M = (read_pass(os.path.join(root, p)) for p in ("pmc_fetch", "pmc_write", "pmc_mfma"))
     ours = lambda k: k and not (k.startswith("void at::") or "rocprim" in k or k.startswith("__amd_rocclr") or "hipcub" in k)
     keys = sorted({k for k in list(F) + list(W) + list(M) if ours(k[0])})
     res = {"_note": "per (kernel, grid): means over the dispatches of `bench.py --steps 1 --warmup 0 --max_new_tokens 6 --no-graph` under three "
                     "separate rocprofv3 --pmc passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH half-count correction); "
                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration",
-           "kernels": []}
+           "_batch_x_ctx": batch_x_ctx, "kernels": []}
     mean = lambda a, c: (a[c][0] / a[c][1]) if c in a and a[c][1] else None
     for k in keys:
         f, w, m = F.get(k, {}), W.get(k, {}), M.get(k, {})
