@@ -12,7 +12,7 @@
 //               tiles of one lane hold: no cross-lane traffic to turn GEMM output into an operand)
 //  * MFMA 16x16x32 C/D map (guide section 3): lane holds D[row = 4*(lane>>4) + i][col = lane & 15], i = 0..3.
 #pragma once
-#define AUR_MAX_BATCH 64     /* decode slots per bank: up to 4 MFMA column groups of 16 batch rows */
+#define AUR_MAX_BATCH 128    /* decode slots per bank: up to 8 MFMA column groups of 16 batch rows (KV at 128 x 2.4k tokens: 156 of 288 GB) */
 #define AUR_SSQ_SLOTS 16     /* stripes of the sum(x^2) accumulators (power of two): decode.hip ssq_to_rstd */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -552,7 +552,11 @@ static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid
 
 template <int NB>
 static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s) {
-    const int N16 = a.Npad >> 4, K32 = a.K >> 5;
+    // chunk depth by column groups: the x ring is NBUF x KC x NB KiB of LDS.  Up to 4 groups (64 rows) KC = 8 (fewest barriers:
+    // 21.6 vs 25.4 us on the QKV shape against KC = 4); 5-8 groups (128 rows) KC = 4 keeps the ring at 128 KiB.
+    constexpr int KC = NB <= 4 ? 8 : 4;
+    constexpr int KCR = NB <= 4 ? 6 : 3, NBUFR = NB <= 4 ? 5 : 4, NLR = NB <= 4 ? 2 : 3;       // split-K residual projection
+    const int N16 = a.Npad >> 4;
     SkxGeom gm{};
     gm.S = 1;
     gm.part = part;
@@ -569,23 +573,22 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             const int pairs = (a.q_cols + a.k_cols) >> 5;
             gm.v_tile0 = (a.q_cols + a.k_cols) >> 4;
             if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
-            if (a.waves == 2) return launch_skx_t<3, 4, SK_QKV, NB, 8, 4, 2, 4>(a, gm, dim3(pairs, 1), s);
-            return launch_skx_t<3, 4, SK_QKV, NB, 8, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
+            if (a.waves == 2) return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 2, 4>(a, gm, dim3(pairs, 1), s);
+            return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
-        case SK_SILU_MUL: return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
-        case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, 8, 4, 4, 4>(a, gm, dim3(split(8), 1), s);
+        case SK_SILU_MUL: return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
+        case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, KC, 4, 4, 4>(a, gm, dim3(split(8), 1), s);
         case SK_ROW: {
             // split-K 4: 4 tiles x 3 k phases per workgroup, N16 / 4 n-blocks x 4 k splits (= 256 workgroups at N = 4096)
             gm.S = 4;
             gm.tiles_lo = 4;
             gm.n_hi = 0;
-            hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, 6, 5, 2, 2>(a, gm, dim3(N16 / 4, 4), s);
+            hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((skinny_row_reduce_kernel<NB>), dim3((N16 + 3) / 4), dim3(256), 0, s, a, gm);
             return hipGetLastError();
         }
     }
-    (void)K32;
     return hipErrorInvalidValue;
 }
 
@@ -627,19 +630,25 @@ static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > AUR_MAX_BATCH || (a.K & 127) || (a.Npad & 31)) return hipErrorInvalidValue;
+    const int nb = (a.B + 15) >> 4;                         // MFMA column groups of 16 batch rows
     if (skinny_lds_applies(a)) {
-        switch ((a.B + 15) >> 4) {
+        switch (nb) {
             case 1: return launch_skx_nb<1>(a, a.part, s);
             case 2: return launch_skx_nb<2>(a, a.part, s);
             case 3: return launch_skx_nb<3>(a, a.part, s);
-            default: return launch_skx_nb<4>(a, a.part, s);
+            case 4: return launch_skx_nb<4>(a, a.part, s);
+            case 5: return launch_skx_nb<5>(a, a.part, s);
+            case 6: return launch_skx_nb<6>(a, a.part, s);
+            case 7: return launch_skx_nb<7>(a, a.part, s);
+            default: return launch_skx_nb<8>(a, a.part, s);
         }
     }
-    switch ((a.B + 15) >> 4) {                              // MFMA column groups of 16 batch rows
+    switch (nb) {                                           // x fragments per wave: engines of <= 32 slots (and K < 8192 residual projections up to 64 rows)
         case 1: return launch_skinny_nb<1>(a, s);
         case 2: return launch_skinny_nb<2>(a, s);
         case 3: return launch_skinny_nb<3>(a, s);
-        default: return launch_skinny_nb<4>(a, s);
+        case 4: return launch_skinny_nb<4>(a, s);
+        default: return hipErrorInvalidValue;               // > 64 rows exist only on the LDS structure (the engine routes every projection there)
     }
 }
 
@@ -934,6 +943,22 @@ __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    if (a.nsplit == 1) {
+        // one split covers the whole context (engines whose batch alone fills the GPU: sequences x heads >= 512 waves): the
+        // wave owns the final softmax, so it writes the attention output itself, straight in x-fragment form (input of the o
+        // projection) - no partials, no combine launch (4.7 us + a kernel boundary per layer-step at 64 sequences)
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int d = 0; d < VD16; ++d) {
+                const int k = head * a.hd + d * 16 + 4 * g;
+                h4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc_o[d][i] / l);
+                *(h4*)(a.out_f + xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)) = o;
+            }
+        }
+        return;
+    }
     if ((lane & 15) == 0) {
 #pragma unroll
         for (int d = 0; d < VD16; ++d) *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
@@ -975,7 +1000,12 @@ hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+bool decode_attention_needs_combine(const DecAttnArgs& a) {
+    // the pipelined kernel finishes single-split problems itself (see its epilogue)
+    return !(a.nsplit == 1 && a.variant == 1 && a.kv.page_tokens == 64);
+}
 hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
+    if (!decode_attention_needs_combine(a)) return hipSuccess;
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.heads, a.B), dim3(a.hd <= 64 ? 64 : 128), 0, s, a);
     return hipGetLastError();
 }

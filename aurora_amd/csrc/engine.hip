@@ -181,11 +181,11 @@ static void derive(aur_ctx* c) {
     c->skinny_variant = g.max_batch > 32 ? 1 : 0;        // a function of the engine's capacity, never of the live batch
     c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch * c->nbanks;
     // decode attention: one wave per (sequence, head, split).  Enough splits to put ~512 waves on the GPU for small batches,
-    // as few as possible (2) once the batch supplies them - every extra split re-reads q, writes a partial and lengthens
+    // as few as possible (1) once the batch supplies them - every extra split re-reads q, writes a partial and lengthens
     // the combine (measured at a 2.2k context: B=64 344 us with 2 splits vs 362 with 10; B=1 15.1 us with 13 vs 24.8 with 38).
     // A function of the engine's capacity only, never of the live batch: results stay batch-invariant per engine.
     int want = (512 + g.llm_heads * g.max_batch - 1) / (g.llm_heads * g.max_batch);
-    want = want < 2 ? 2 : (want > 16 ? 16 : want);
+    want = want < 1 ? 1 : (want > 16 ? 16 : want);          // 1 split (>= 512 sequence-heads): 333.6 us vs 333.4 us with 2 at 64 x 32, and no combine
     c->pps = (c->l_max_pages + want - 1) / want;
     if (c->pps < 1) c->pps = 1;
     c->nsplit = (c->l_max_pages + c->pps - 1) / c->pps;
@@ -902,7 +902,7 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     SkinnyArgs o{};
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
     o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
-    o.variant = ctx->skinny_variant; o.part = d >= ctx->row_split_min_k ? ctx->d_part_row : nullptr;
+    o.variant = ctx->skinny_variant; o.part = (d >= ctx->row_split_min_k || ctx->cfg.max_batch > 64) ? ctx->d_part_row : nullptr;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -920,7 +920,7 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     SkinnyArgs dn{};
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
     dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
-    dn.variant = ctx->skinny_variant; dn.part = g.llm_mlp >= ctx->row_split_min_k ? ctx->d_part_row : nullptr;
+    dn.variant = ctx->skinny_variant; dn.part = (g.llm_mlp >= ctx->row_split_min_k || g.max_batch > 64) ? ctx->d_part_row : nullptr;
     return dn;
 }
 
@@ -1050,6 +1050,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
     else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);
+    else if (!strcmp(name, "gemm_wide_epilogue")) gemm256_set_wide_epilogue((int)value);
 
     else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             g2_prologue(a, src, smem, w);
         }
         // 16-byte row accesses need 8-column alignment of every row (ldc, ldr multiples of 8 halves; SiLU*up writes n / 2: ldc % 4)
-        const bool wide = EPI == EPI_ROW && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
+        const bool wide = EPI == EPI_ROW && a.wide_epilogue && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
         if (wide) g2_epilogue_row(a, acc, mb, nb, lane, w, smem);
         else gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
     }
@@ -348,7 +348,12 @@ bool gemm256_eligible(const GemmArgs& a) {
 static int g_gemm256_max_wgs = 0;
 void gemm256_set_max_wgs(int n) { g_gemm256_max_wgs = n > 0 ? (n + 7) & ~7 : 0; }
 
-hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
+static int g_gemm256_wide = 1;
+void gemm256_set_wide_epilogue(int on) { g_gemm256_wide = on; }
+
+hipError_t launch_gemm256(const GemmArgs& a_in, int epi, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.wide_epilogue = g_gemm256_wide;
     int ntiles = (a.Npad >> 8) * ((a.M + 255) >> 8);
     const int cap = g_gemm256_max_wgs > 0 ? g_gemm256_max_wgs : (g_gemm256_cus & ~7);     // one 160 KiB workgroup per CU
     if (ntiles > cap) ntiles = cap;

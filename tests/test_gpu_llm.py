@@ -227,3 +227,37 @@ def test_prefill_gemm256_equals_gemm128():
     finally:
         eng.set_option("gemm_mode", 1)
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["hd32", "hd128"])
+def test_single_split_decode_attention_finishes_in_the_kernel(name):
+    """Engines whose batch alone fills the GPU run decode attention with ONE split per (sequence, head): the kernel then
+    normalises and writes the x-fragment output itself and the combine launch disappears.  Forced here on a small engine
+    (dec_attn_pps beyond the context); logits vs the oracle, hipGraph == eager, batch of ragged sequences == each alone."""
+    cfg = LLM_CFGS[name]
+    gen = torch.Generator().manual_seed(17)
+    lens = [37, 150, 64]
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
+    outs = {}
+    for use_graph in (False, True):
+        eng, w = make_engine(cfg, 11, max_batch=3, use_graph=use_graph)
+        try:
+            eng.set_option("dec_attn_pps", 1 << 20)
+            outs[use_graph] = eng.generate([padded(e) for e in embs], lens, 12, eos_id=None)
+            if not use_graph:
+                alone = [eng.generate([padded(e)], [L], 12, eos_id=None)[0] for e, L in zip(embs, lens)]
+                assert outs[False] == alone
+                eng.begin_batch(1, 6, None)
+                eng.prefill(0, padded(embs[1]), lens[1])
+                logits = [eng.logits()[0].cpu()]
+                for _ in range(5):
+                    eng.decode(1)
+                    logits.append(eng.logits()[0].cpu())
+                ids = eng.outputs()[0]
+                ref = teacher_forced_logits(embs[1], ids, w, cfg)
+                scale = ref.abs().max().item()
+                for i in range(6):
+                    assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, i
+        finally:
+            eng.close()
+    assert outs[False] == outs[True]

@@ -16,14 +16,15 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def eng():
     from aurora_amd.engine import AuroraCapEngine
-    e = AuroraCapEngine({"vit": None, "llm": None}, {}, max_frames=1, max_batch=64)
+    e = AuroraCapEngine({"vit": None, "llm": None}, {}, max_frames=1, max_batch=128)
     e.set_option("skinny_variant", 1)
     yield e
     e.close()
 
 
 @pytest.mark.parametrize("b,k,n", [(1, 128, 320), (16, 256, 512), (17, 384, 1000), (33, 4096, 1024), (48, 1024, 4096),
-                                   (64, 4096, 2048), (64, 11008, 256), (40, 128, 48), (64, 2048, 16)])
+                                   (64, 4096, 2048), (64, 11008, 256), (40, 128, 48), (64, 2048, 16), (65, 256, 320),
+                                   (100, 4096, 1024), (128, 1024, 512), (128, 11008, 128)])
 def test_projection_through_lds_vs_fp32(eng, b, k, n):
     g = torch.Generator().manual_seed(b * 7 + k + n)
     a = (torch.randn(b, k, generator=g) * 0.5).half()
@@ -76,8 +77,8 @@ def test_decode_logits_vs_oracle_and_vs_the_per_wave_structure(name):
         assert (got[0][1][i] - logits[i]).abs().max().item() <= 5e-3 * scale, i
 
 
-@pytest.mark.parametrize("B", [20, 40, 64])
-def test_batch_invariance_and_graph_at_two_to_four_column_groups(B):
+@pytest.mark.parametrize("B", [20, 40, 64, 90, 128])
+def test_batch_invariance_and_graph_at_two_to_eight_column_groups(B):
     cfg = LLM_CFGS["hd64"]
     gen = torch.Generator().manual_seed(B)
     lens = [33 + (7 * i) % 90 for i in range(B)]

@@ -82,10 +82,16 @@ def main():
                 run(f"attn v{variant} pps{pps}", ["dec_attn"])
     else:
         run("attn v1 pps4", ["dec_attn"])
-    for mode, tag in ((0, "prefill gemm128"), (2, "prefill gemm256")):
+    for mode, wide, tag in ((0, 1, "prefill gemm128"), (2, 0, "prefill gemm256 direct stores"), (2, 1, "prefill gemm256 LDS epilogue")):
         eng.set_option("gemm_mode", mode)
+        eng.set_option("gemm_wide_epilogue", wide)
         run(tag, ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
     eng.set_option("gemm_mode", 1)
+    if not args.quick:
+        eng.set_option("dec_attn_variant", 1)
+        for pps in (19, 38, 64):
+            eng.set_option("dec_attn_pps", pps)
+            run(f"attn v1 pps{pps}", ["dec_attn"])
     run("prefill", ["pre_norm", "pre_attn"])
     print(json.dumps(res))
     eng.close()
