@@ -573,10 +573,13 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             const int pairs = (a.q_cols + a.k_cols) >> 5;
             gm.v_tile0 = (a.q_cols + a.k_cols) >> 4;
             if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
+            if (NB > 4 && a.ring == 1) return launch_skx_t<3, 4, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
             if (a.waves == 2) return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 2, 4>(a, gm, dim3(pairs, 1), s);
             return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
-        case SK_SILU_MUL: return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
+        case SK_SILU_MUL:
+            if (NB > 4 && a.ring == 1) return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 2, 4, 4>(a, gm, dim3(split(6), 1), s);
+            return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
         case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, KC, 4, 4, 4>(a, gm, dim3(split(8), 1), s);
         case SK_ROW: {
             // split-K 4: 4 tiles x 3 k phases per workgroup, N16 / 4 n-blocks x 4 k splits (= 256 workgroups at N = 4096)

@@ -69,7 +69,7 @@ struct aur_ctx {
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
-    int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4;                             // decode projections: x through LDS (engines of > 32 slots)
+    int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
@@ -886,7 +886,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.waves = ctx->qkv_depth;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.waves = ctx->qkv_depth; q.ring = ctx->skinny_ring;
     return q;
 }
 static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
@@ -911,7 +911,7 @@ static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     SkinnyArgs gu{};
     gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
     gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
-    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant; gu.ring = ctx->skinny_ring;
     return gu;
 }
 static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
@@ -1047,6 +1047,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
     else if (!strcmp(name, "skinny_qkv_depth")) ctx->qkv_depth = (int)value;
+    else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
     else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);

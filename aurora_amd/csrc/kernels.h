@@ -137,6 +137,7 @@ struct SkinnyArgs {
     // structure: 0 = x fragments per wave from L2 (engines of <= 32 decode slots), 1 = x through LDS once per workgroup
     // (decode.hip "skinny GEMM, x through LDS").  Chosen per ENGINE (capacity), never per live batch: batch invariance.
     int variant;
+    int ring;               // variant 1, > 64 rows: 0 = 4 x (4 k32) x-ring buffers, 1 = 2 x (8 k32): fewer barriers, measured 52.4 vs 55.8 us (QKV) and 46.2 vs 49.7 us (gate/up) at 128 rows
     float* part;            // variant 1, SK_ROW: split-K partials [4][Npad/16][ceil(B/16)][64][4] fp32 (nullptr: keep structure 0)
 };
 enum { SK_ROW = 0, SK_LOGITS = 1, SK_SILU_MUL = 2, SK_QKV = 3 };

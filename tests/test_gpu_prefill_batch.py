@@ -80,7 +80,7 @@ def test_batch_of_52_four_column_groups_equals_single():
         eng.close()
     from aurora_amd._lib import AuroraHipError
     with pytest.raises(AuroraHipError):
-        make_engine(cfg, 13, max_batch=65)
+        make_engine(cfg, 13, max_batch=129)                 # the slot cap (AUR_MAX_BATCH: 8 MFMA column groups)
 
 
 def test_batch_of_20_two_column_groups_equals_single():

@@ -63,13 +63,17 @@ def main():
             print(f"{tag:28s} {k:12s} {us:9.2f} us  {rate:9.1f} {unit}", flush=True)
 
     dec = ["dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
-    for variant, tag in ((0, "decode x-per-wave"), (1, "decode x-through-LDS")):
+    for variant, tag in ((0, "decode x-per-wave"), (1, "decode x-through-LDS"))[(1 if B > 64 else 0):]:
         eng.set_option("skinny_variant", variant)
         run(tag, dec)
     eng.set_option("skinny_variant", 1)
     eng.set_option("skinny_qkv_depth", 2)
     run("x-through-LDS qkv depth 2", ["dec_qkv"])
     eng.set_option("skinny_qkv_depth", 4)
+    if B > 64:
+        eng.set_option("skinny_ring", 1)
+        run("x-through-LDS ring 2 x 8", ["dec_qkv", "dec_gateup"])
+        eng.set_option("skinny_ring", 0)
     eng.set_option("skinny_variant", 1 if B > 32 else 0)
     if not args.quick:
         for nw in (4, 8):
