@@ -729,14 +729,12 @@ __global__ __launch_bounds__(64 * NWV) void xfrag_norm_kernel(const half_t* __re
     }
 }
 
-int g_xfrag_norm_waves = 16;
 hipError_t launch_xfrag_norm(const half_t* x, int64_t ldx, const float* w, float eps, int rows, int d, int b0, half_t* xf,
-                             unsigned long long* ssq_out, hipStream_t s) {
+                             unsigned long long* ssq_out, hipStream_t s, int waves) {
     if ((d & 31) || rows < 1) return hipErrorInvalidValue;
     const int g0 = b0 >> 4, g1 = (b0 + rows - 1) >> 4;
-    extern int g_xfrag_norm_waves;
-    if (g_xfrag_norm_waves == 16) hipLaunchKernelGGL(xfrag_norm_kernel<16>, dim3(g1 - g0 + 1), dim3(1024), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
-    else if (g_xfrag_norm_waves == 8) hipLaunchKernelGGL(xfrag_norm_kernel<8>, dim3(g1 - g0 + 1), dim3(512), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
+    if (waves == 16) hipLaunchKernelGGL(xfrag_norm_kernel<16>, dim3(g1 - g0 + 1), dim3(1024), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
+    else if (waves == 8) hipLaunchKernelGGL(xfrag_norm_kernel<8>, dim3(g1 - g0 + 1), dim3(512), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
     else hipLaunchKernelGGL(xfrag_norm_kernel<4>, dim3(g1 - g0 + 1), dim3(256), 0, s, x, ldx, w, eps, rows, d, b0, xf, ssq_out);
     return hipGetLastError();
 }

@@ -69,6 +69,7 @@ struct aur_ctx {
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
+    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr;
@@ -118,7 +119,16 @@ static int aur_fail(aur_ctx* ctx, int code, const char* fmt, ...) {
     } while (0)
 
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+// every GEMM of a ctx goes through here: the ctx's tuning knobs travel in the argument block (no process-global state)
+static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t s);
 static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t s) {
+    a.gemm_mode = ctx->gemm_mode;
+    a.max_wgs = ctx->gemm_max_wgs;
+    a.wide_epilogue = ctx->gemm_wide;
+    return launch_gemm(a, epi, s);
+}
 
 // ------------------------------------------------------------------------------------------ schedule
 extern "C" int32_t aur_tome_r(int32_t height, int32_t width, int32_t patch, double ratio, int32_t layers) {
@@ -540,7 +550,7 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     q.A = ctx->w_xn; q.lda = D; q.W = w.qkv_w; q.bias = w.qkv_b; q.M = M; q.Npad = ctx->v_qkv_npad; q.K = D;
     q.rows_per_seq = t_pad; q.q_cols = ctx->v_qcols; q.k_cols = ctx->v_qcols; q.hd = ctx->v_hd; q.Qf = ctx->w_qf;
     q.kv = vit_kv(ctx, t_pad); q.rope = nullptr; q.pos0 = 0; q.seq0 = 0; q.tag = GT_VIT_QKV;
-    CK(launch_gemm(q, EPI_QKV, s));                                                        // aurora.py:634-636
+    CK(ctx_gemm(ctx, q, EPI_QKV, s));                                                        // aurora.py:634-636
     AttnArgs at{};
     at.Qf = ctx->w_qf; at.kv = q.kv; at.seq0 = 0; at.nseq = F; at.heads = g.vit_heads; at.rows_per_seq = t_pad; at.t = t;
     at.causal = 0; at.scale = 1.0f / sqrtf((float)ctx->v_hd); at.O = ctx->w_attn; at.ldo = D; at.hd = ctx->v_hd;
@@ -548,7 +558,7 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     GemmArgs o{};
     o.A = ctx->w_attn; o.lda = D; o.W = w.out_w; o.bias = w.out_b; o.M = M; o.Npad = ctx->v_dpad; o.K = D;
     o.C = x; o.ldc = D; o.resid = x; o.ldr = D; o.n_real = D; o.act = ACT_NONE; o.tag = GT_VIT_OUT;
-    CK(launch_gemm(o, EPI_ROW, s));                                                        // aurora.py:699, 743
+    CK(ctx_gemm(ctx, o, EPI_ROW, s));                                                        // aurora.py:699, 743
     int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;                                            // tome.py:45
     half_t* xc = x;
     const float* sc = size;
@@ -570,11 +580,11 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     GemmArgs f1{};
     f1.A = ctx->w_xn; f1.lda = D; f1.W = w.fc1_w; f1.bias = w.fc1_b; f1.M = M2; f1.Npad = ctx->v_mlp_pad; f1.K = D;
     f1.C = ctx->w_h; f1.ldc = g.vit_mlp; f1.n_real = g.vit_mlp; f1.act = g.vit_act == AUR_ACT_GELU ? ACT_GELU : ACT_QUICK_GELU; f1.tag = GT_VIT_FC1;
-    CK(launch_gemm(f1, EPI_ROW, s));
+    CK(ctx_gemm(ctx, f1, EPI_ROW, s));
     GemmArgs f2{};
     f2.A = ctx->w_h; f2.lda = g.vit_mlp; f2.W = w.fc2_w; f2.bias = w.fc2_b; f2.M = M2; f2.Npad = ctx->v_dpad; f2.K = g.vit_mlp;
     f2.C = xc; f2.ldc = D; f2.resid = xc; f2.ldr = D; f2.n_real = D; f2.act = ACT_NONE; f2.tag = GT_VIT_FC2;
-    CK(launch_gemm(f2, EPI_ROW, s));                                                       // aurora.py:751-752
+    CK(ctx_gemm(ctx, f2, EPI_ROW, s));                                                       // aurora.py:751-752
     *x_res = xc;
     *size_res = sc;
     *t_out = t2;
@@ -600,7 +610,7 @@ extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frame
     GemmArgs pe{};
     pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * npatch;
     pe.Npad = ctx->v_dpad; pe.K = ctx->v_kpad; pe.C = ctx->w_patch; pe.ldc = D; pe.n_real = D; pe.act = ACT_NONE;
-    CK(launch_gemm(pe, EPI_ROW, s));
+    CK(ctx_gemm(ctx, pe, EPI_ROW, s));
     CK(launch_vit_assemble(ctx->w_patch, ctx->v_cls, pos_emb ? (const half_t*)pos_emb : ctx->v_pos, ctx->v_preln_w, ctx->v_preln_b,
                            g.vit_ln_eps, frames, npatch, D, rup(t0, 32), ctx->w_xa, s));
     half_t* x = ctx->w_xa;
@@ -703,7 +713,7 @@ extern "C" int aur_linear(aur_ctx* ctx, const void* a, int32_t m, int32_t k, con
     g.A = (const half_t*)a; g.lda = k; g.W = (const half_t*)w_packed; g.bias = bias; g.M = m; g.Npad = npad; g.K = k;
     g.C = (half_t*)c; g.ldc = n; g.resid = (const half_t*)resid; g.ldr = n; g.n_real = n;
     g.act = act == AUR_ACT_GELU ? ACT_GELU : act == AUR_ACT_QUICK_GELU ? ACT_QUICK_GELU : ACT_NONE;
-    CK(launch_gemm(g, EPI_ROW, (hipStream_t)stream));
+    CK(ctx_gemm(ctx, g, EPI_ROW, (hipStream_t)stream));
     return AUR_OK;
 }
 extern "C" int aur_linear_skinny(aur_ctx* ctx, const void* a, int32_t m, int32_t k, const void* w_packed, int32_t npad,
@@ -744,11 +754,11 @@ extern "C" int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, c
         GemmArgs a{};
         a.A = (const half_t*)vis; a.lda = g.vit_hidden; a.W = ctx->p_fc1_w; a.bias = ctx->p_fc1_b; a.M = nvis; a.Npad = ctx->l_dpad;
         a.K = g.vit_hidden; a.C = ctx->l_p1; a.ldc = d; a.n_real = d; a.act = ACT_GELU;
-        CK(launch_gemm(a, EPI_ROW, s));                                   // modeling_projector.py:20-33 (erf GELU)
+        CK(ctx_gemm(ctx, a, EPI_ROW, s));                                   // modeling_projector.py:20-33 (erf GELU)
         GemmArgs b{};
         b.A = ctx->l_p1; b.lda = d; b.W = ctx->p_fc2_w; b.bias = ctx->p_fc2_b; b.M = nvis; b.Npad = ctx->l_dpad; b.K = d;
         b.C = (half_t*)embeds; b.ldc = d; b.n_real = d; b.act = ACT_NONE; b.out_rows = vis_rows;
-        CK(launch_gemm(b, EPI_ROW, s));                                   // written straight into the spliced rows
+        CK(ctx_gemm(ctx, b, EPI_ROW, s));                                   // written straight into the spliced rows
     }
     CK(launch_embed_rows(ctx->l_embed, d, text_ids, text_rows, ntext, (half_t*)embeds, d, s));   // utils.py:214-216
     stage_end(ctx, "project", s);
@@ -822,7 +832,7 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
         q.A = ctx->l_xn; q.lda = d; q.W = w.qkv_w; q.bias = nullptr; q.M = M; q.Npad = ctx->l_qkv_npad; q.K = d;
         q.rows_per_seq = Mseq; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.Qf = ctx->l_qf; q.kv = llm_kv(ctx, l);
         q.rope = ctx->l_rope; q.pos0 = 0; q.seq0 = slot; q.tag = GT_LLM_QKV;
-        CK(launch_gemm(q, EPI_QKV, s));
+        CK(ctx_gemm(ctx, q, EPI_QKV, s));
     }
     if (which & 4) {
         AttnArgs at{};
@@ -834,20 +844,20 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
         GemmArgs o{};
         o.A = ctx->l_attn; o.lda = d; o.W = w.o_w; o.M = M; o.Npad = ctx->l_dpad; o.K = d; o.C = x; o.ldc = d; o.resid = x; o.ldr = d;
         o.n_real = d; o.act = ACT_NONE; o.tag = GT_LLM_O;
-        CK(launch_gemm(o, EPI_ROW, s));
+        CK(ctx_gemm(ctx, o, EPI_ROW, s));
     }
     if (which & 16) CK(launch_rmsnorm(x, d, nullptr, g.llm_rms_eps, M, d, ctx->l_xn, d, s));     // weight folded into gateup.w
     if (which & 32) {
         GemmArgs gu{};
         gu.A = ctx->l_xn; gu.lda = d; gu.W = w.gateup_w; gu.M = M; gu.Npad = ctx->l_gu_npad; gu.K = d; gu.C = ctx->l_h; gu.ldc = g.llm_mlp;
         gu.n_real = 2 * g.llm_mlp; gu.act = ACT_SILU_MUL; gu.tag = GT_LLM_GATEUP;
-        CK(launch_gemm(gu, EPI_ROW, s));
+        CK(ctx_gemm(ctx, gu, EPI_ROW, s));
     }
     if (which & 64) {
         GemmArgs dn{};
         dn.A = ctx->l_h; dn.lda = g.llm_mlp; dn.W = w.down_w; dn.M = M; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp; dn.C = x; dn.ldc = d;
         dn.resid = x; dn.ldr = d; dn.n_real = d; dn.act = ACT_NONE; dn.tag = GT_LLM_DOWN;
-        CK(launch_gemm(dn, EPI_ROW, s));
+        CK(ctx_gemm(ctx, dn, EPI_ROW, s));
     }
     return AUR_OK;
 }
@@ -1049,9 +1059,9 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "skinny_qkv_depth")) ctx->qkv_depth = (int)value;
     else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
-    else if (!strcmp(name, "gemm_mode")) gemm_set_mode((int)value);
-    else if (!strcmp(name, "gemm_max_wgs")) gemm256_set_max_wgs((int)value);
-    else if (!strcmp(name, "gemm_wide_epilogue")) gemm256_set_wide_epilogue((int)value);
+    else if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
+    else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
+    else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
 
     else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {

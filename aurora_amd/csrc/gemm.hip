@@ -247,11 +247,9 @@ hipError_t gemm_init() {
     return hipFuncSetAttribute((const void*)gemm_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
 }
 
-static int g_gemm_mode = 1;
-void gemm_set_mode(int mode) { g_gemm_mode = mode; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if ((g_gemm_mode == 1 && gemm256_eligible(a)) || (g_gemm_mode == 2 && (a.Npad & 255) == 0)) return launch_gemm256(a, epi, s);
+    if ((a.gemm_mode == 1 && gemm256_eligible(a)) || (a.gemm_mode == 2 && (a.Npad & 255) == 0)) return launch_gemm256(a, epi, s);
     const int nbn = a.Npad / BN, nbm = (a.M + BM - 1) / BM;
     dim3 grid(nbn * nbm), block(256);
     if (epi == EPI_ROW)

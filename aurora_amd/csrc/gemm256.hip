@@ -345,17 +345,9 @@ bool gemm256_eligible(const GemmArgs& a) {
     return tiles >= 224;
 }
 
-static int g_gemm256_max_wgs = 0;
-void gemm256_set_max_wgs(int n) { g_gemm256_max_wgs = n > 0 ? (n + 7) & ~7 : 0; }
-
-static int g_gemm256_wide = 1;
-void gemm256_set_wide_epilogue(int on) { g_gemm256_wide = on; }
-
-hipError_t launch_gemm256(const GemmArgs& a_in, int epi, hipStream_t s) {
-    GemmArgs a = a_in;
-    a.wide_epilogue = g_gemm256_wide;
+hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     int ntiles = (a.Npad >> 8) * ((a.M + 255) >> 8);
-    const int cap = g_gemm256_max_wgs > 0 ? g_gemm256_max_wgs : (g_gemm256_cus & ~7);     // one 160 KiB workgroup per CU
+    const int cap = a.max_wgs > 0 ? ((a.max_wgs + 7) & ~7) : (g_gemm256_cus & ~7);        // one 160 KiB workgroup per CU
     if (ntiles > cap) ntiles = cap;
     dim3 grid(ntiles), block(512);
 #define G2_LAUNCH(E, T) hipLaunchKernelGGL((gemm256_kernel<E, T>), grid, block, G2_LDS, s, a)

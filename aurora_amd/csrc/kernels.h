@@ -28,7 +28,10 @@ struct GemmArgs {
     const float2* rope;     // [pos][hd/2] (cos, sin) or nullptr
     int pos0;               // position of row 0 of each sequence (multiple of 32)
     int seq0;               // first sequence's row in the page table
-    int wide_epilogue;      // 256x256 kernel: LDS-transposed full-line epilogue (set by launch_gemm256; bit-identical to the direct one)
+    // ---- per-ctx tuning knobs (aur_set_option; filled by the engine at every launch - nothing is process-global)
+    int gemm_mode;          // 0: 128x128 kernel only, 1: auto, 2: force 256x256 when Npad % 256 == 0
+    int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
+    int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
                             // grid is the same for every shape) separate the shapes - profiles/*_kernel_stats.txt, *_pmc.json
@@ -44,9 +47,6 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 hipError_t gemm256_init();
 bool gemm256_eligible(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
-void gemm256_set_wide_epilogue(int on);   // 1 (default): LDS-transposed full-line stores; 0: direct 8-byte stores (A/B knob)
-void gemm256_set_max_wgs(int n);  // > 0: persistent 256x256 GEMM on at most n workgroups (= CUs); 0: one workgroup per tile
-void gemm_set_mode(int mode);      // 0: 128x128 kernel only, 1: auto (default), 2: force 256 when Npad % 256 == 0
 hipError_t launch_pack_weight(const half_t* w, int n_src, int k_src, int ld_src, const int32_t* row_map, int npad,
                               int kpad, half_t* out, hipStream_t s);
 
@@ -144,7 +144,7 @@ enum { SK_ROW = 0, SK_LOGITS = 1, SK_SILU_MUL = 2, SK_QKV = 3 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 // xf[b0 + row] = RMSNorm(x[row]) (w != nullptr) or x[row], in x-fragment form; x rows are ldx halves apart
 hipError_t launch_xfrag_norm(const half_t* x, int64_t ldx, const float* w, float eps, int rows, int d, int b0, half_t* xf,
-                             unsigned long long* ssq_out, hipStream_t s);
+                             unsigned long long* ssq_out, hipStream_t s, int waves = 16);
 hipError_t launch_xfrag_pack(const half_t* x, int64_t ldx, int rows, int d, half_t* xf, hipStream_t s);
 
 struct DecAttnArgs {

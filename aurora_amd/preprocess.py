@@ -45,19 +45,31 @@ def read_video_pyav(path: str, num_frm: int = 8):
         import av
     except ImportError as e:
         raise RuntimeError("PyAV (`av`) is required to decode video input") from e
-    container = av.open(path)
-    total = 0 if ("webm" in path or "mkv" in path) else container.streams.video[0].frames
-    if total <= 0:
-        frames = [f for f in container.decode(video=0)]
+    def by_packets():
+        """load_video.py:21-28, 48-56: decode every frame, then sample - webm / mkv, streams without a frame count, and the
+        reference's bare `except:` fall-back when the stream path fails on an mp4 (bad index, truncated file)."""
+        frames = [f for f in av.open(path).decode(video=0)]
         return np.stack([frames[i].to_ndarray(format="rgb24") for i in sample_frame_indices(len(frames), num_frm)])
-    idx = sample_frame_indices(total, num_frm)
-    want, out = set(idx), {}
-    for i, frame in enumerate(container.decode(video=0)):
-        if i in want:
-            out[i] = frame.to_ndarray(format="rgb24")
-        if i >= idx[-1]:
-            break
-    return np.stack([out[i] for i in idx if i in out])
+
+    if "webm" in path or "mkv" in path:
+        return by_packets()
+    try:                                                           # load_video.py:35-47: "for mp4, we try loading with stream first"
+        container = av.open(path)
+        total = container.streams.video[0].frames
+        if total <= 0:
+            return by_packets()
+        idx = sample_frame_indices(total, num_frm)
+        want, out = set(idx), {}
+        for i, frame in enumerate(container.decode(video=0)):
+            if i in want:
+                out[i] = frame.to_ndarray(format="rgb24")
+            if i >= idx[-1]:
+                break
+        if len(out) != len(idx):                                   # the header promised more frames than the stream holds
+            return by_packets()
+        return np.stack([out[i] for i in idx])
+    except Exception:                                              # noqa: BLE001 - the reference catches everything here too
+        return by_packets()
 
 
 def host_plan(in_h: int, in_w: int, image: int = 378) -> np.ndarray:

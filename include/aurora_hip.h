@@ -64,7 +64,8 @@ const char* aur_last_error(const aur_ctx* ctx);   /* ctx may be NULL: returns th
 const char* aur_version(void);
 
 /* Named device tensors (weights in kernel layout).  Replaces the three from_pretrained loads at
- * inference.py:46-57.  Names: see aurora_amd/weights.py (e.g. "vit.3.qkv.w", "llm.7.down.w"). */
+ * inference.py:46-57.  Names and layouts: aurora_amd/engine.py::_load_vit / _load_llm / _load_projector
+ * (e.g. "vit.3.qkv.w", "llm.7.down.w", "proj.fc1.b"). */
 int aur_set_tensor(aur_ctx* ctx, const char* name, const void* dev_ptr, int64_t nbytes);
 /* Caller-owned scratch; sizes from the two queries (depend only on cfg). */
 int64_t aur_workspace_bytes(const aur_ctx* ctx);
@@ -179,8 +180,11 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 /* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 0/1, "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
- * "microbench_prefill_nseq" sequences per pass for the pre_* microbenchmarks.  The gemm_* knobs are bit-neutral; the
- * dec_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
+ * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
+ * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_qkv_depth", "skinny_ring",
+ * "microbench_prefill_nseq" sequences per pass for the pre_* microbenchmarks.  Every knob is state of THIS ctx.  The gemm_*
+ * knobs are bit-neutral; the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not
+ * bit-comparable across settings). */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
 /* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
  * kernel in {dec_norm, dec_qkv, dec_attn, dec_o, dec_gateup, dec_down, dec_lm_head, pre_norm, pre_qkv, pre_attn,

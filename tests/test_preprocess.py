@@ -94,3 +94,51 @@ def test_plan_rejects_bad_sizes_and_lut_matches_oracle():
     assert np.array_equal(normalise_lut().view(np.uint16), R.normalise_lut().view(np.uint16))
     m, s = (0.5, 0.4, 0.3), (0.2, 0.25, 0.3)
     assert np.array_equal(normalise_lut(m, s).view(np.uint16), R.normalise_lut(m, s).view(np.uint16))
+
+
+def test_read_video_pyav_falls_back_to_packet_decode(monkeypatch):
+    """load_video.py:35-56: mp4s go through the stream path first; ANY failure there (the reference uses a bare `except:`) and
+    every webm / mkv decode all frames and sample afterwards.  A fake `av` stands in for PyAV (not installed here)."""
+    import sys
+    import types
+    from aurora_amd import preprocess as P
+
+    class Frame:
+        def __init__(self, i):
+            self.i = i
+
+        def to_ndarray(self, format):
+            return np.full((2, 2, 3), self.i, np.uint8)
+
+    class Container:
+        def __init__(self, nframes, header, broken_stream):
+            self.nframes, self.broken = nframes, broken_stream
+            self.streams = types.SimpleNamespace(video=[types.SimpleNamespace(frames=header)])
+            self.decodes = 0
+
+        def decode(self, video=0):
+            self.decodes += 1
+            if self.broken and self.decodes == 1:
+                raise OSError("corrupt index")
+            return iter([Frame(i) for i in range(self.nframes)])
+
+    opened = []
+
+    def make_av(nframes, header, broken=False):
+        def open_(path):
+            c = Container(nframes, header, broken and not opened)
+            opened.append(c)
+            return c
+        return types.SimpleNamespace(open=open_)
+
+    def frames_of(path, nframes, header, broken=False, num_frm=4):
+        opened.clear()
+        monkeypatch.setitem(sys.modules, "av", make_av(nframes, header, broken))
+        return [int(f[0, 0, 0]) for f in P.read_video_pyav(path, num_frm)]
+
+    want = P.sample_frame_indices(20, 4)                          # [0, 6, 12, 19]
+    assert frames_of("clip.mp4", 20, 20) == want                  # stream path
+    assert frames_of("clip.mp4", 20, 20, broken=True) == want     # stream path raises -> packet decode (second open)
+    assert frames_of("clip.mp4", 20, 0) == want                   # no frame count in the header
+    assert frames_of("clip.mp4", 12, 20) == P.sample_frame_indices(12, 4)     # header promises more frames than exist
+    assert frames_of("clip.webm", 20, 20) == want and frames_of("clip.mkv", 20, 20) == want

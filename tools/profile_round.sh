@@ -8,19 +8,24 @@
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline"
+if [ "$2" != "pmc" ]; then
 for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside a kernel launch: retry
   rm -rf "$OUT/trace"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 1 --warmup 0 --decode-chunk 64 > "$OUT/trace.log" 2>&1 && break
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
-SHORT="$BENCH --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --batch-mode"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $SHORT > "$OUT/pmc_fetch.log" 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $SHORT > "$OUT/pmc_write.log" 2>&1
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- $SHORT > "$OUT/pmc_mfma.log" 2>&1
+fi
+# counters serialise every dispatch: 64 clips keep the three passes at a few minutes (per-launch shapes of the front end are
+# those of the default run - prefill groups of 8, ViT chunks of 16 -; the decode kernels are profiled at 64 rows)
+SHORT="$BENCH --batch 64 --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --batch-mode"
+timeout 1500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $SHORT > "$OUT/pmc_fetch.log" 2>&1
+timeout 1500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $SHORT > "$OUT/pmc_write.log" 2>&1
+timeout 1500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- $SHORT > "$OUT/pmc_mfma.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT" "$OUT/${TAG}_pmc.json" > "$OUT/${TAG}_pmc_summary.txt" 2>&1
 # keep the merge-back under 64 MiB: drop the raw per-dispatch csv / db files, keep logs + summaries
 for f in $(find "$OUT" -name "*counter_collection.csv" | head -3); do head -3 "$f" > "$f.head.txt"; done
