@@ -68,11 +68,11 @@ struct SkPre {
     half_t* page[NB];
 };
 template <int MODE, int NB>
-__device__ __forceinline__ void skinny_prefetch(const SkinnyArgs& a, const int lane, SkPre<NB>& pre, const int tile0 = 0) {
+__device__ __forceinline__ void skinny_prefetch(const SkinnyArgs& a, const int lane, SkPre<NB>& pre, const int tile0 = 0, const int nb_base = 0) {
     const int c = lane & 15;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int b = nb * 16 + c;
+        const int b = (nb_base + nb) * 16 + c;
         const bool live = b >= a.b_lo && b < a.b_hi;
         pre.rstd[nb] = (a.ssq_in && live) ? ssq_to_rstd(a.ssq_in, b, a.K, a.norm_eps) : 1.f;
         pre.pos[nb] = 0;
@@ -85,11 +85,12 @@ __device__ __forceinline__ void skinny_prefetch(const SkinnyArgs& a, const int l
 }
 
 template <int NT, int MODE, int NB>
-__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile0, f4 (&acc)[NT][NB], const int lane, const SkPre<NB>& pre) {
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile0, f4 (&acc)[NT][NB], const int lane, const SkPre<NB>& pre,
+                                             const int nb_base = 0) {
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int b = nb * 16 + c;
+        const int b = (nb_base + nb) * 16 + c;
         if (b < a.b_lo || b >= a.b_hi) continue;
         if (a.ssq_in) {                                   // folded RMSNorm: per-row 1/rms of the (un-normalised) input
             const float rstd = pre.rstd[nb];
@@ -510,27 +511,25 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     skinny_store<1, MODE, NB>(a, tile, one, lane, pre);
 }
 
-// second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue
-template <int NB>
-__global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, SkxGeom gm) {
+// second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue.
+// One wave per (n16 tile, column group): N16 x NB waves (2048 at 128 rows) - the first version walked the NB groups inside a
+// wave (64 workgroups in all: 9.4 us per launch at 128 rows, twice per layer).
+__global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, SkxGeom gm, int NB) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int N16 = a.Npad >> 4;
-    if (tile >= N16) return;
-    SkPre<NB> pre;
-    skinny_prefetch<SK_ROW, NB>(a, lane, pre);
-    f4 acc[1][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[0][nb] = *(const f4*)(gm.part + (((int64_t)tile * NB + nb) * 64 + lane) * 4);
+    if (idx >= N16 * NB) return;
+    const int tile = idx / NB, nb = idx - tile * NB;
+    SkPre<1> pre;
+    skinny_prefetch<SK_ROW, 1>(a, lane, pre, tile, nb);
+    f4 acc[1][1];
+    acc[0][0] = *(const f4*)(gm.part + (((int64_t)tile * NB + nb) * 64 + lane) * 4);
     for (int s = 1; s < gm.S; ++s) {
+        const f4 q = *(const f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f4 q = *(const f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[0][nb][i] += q[i];
-        }
+        for (int i = 0; i < 4; ++i) acc[0][0][i] += q[i];
     }
-    skinny_store<1, SK_ROW, NB>(a, tile, acc, lane, pre);
+    skinny_store<1, SK_ROW, 1>(a, tile, acc, lane, pre, nb);
 }
 
 static int g_skx_cus = 256;
@@ -588,7 +587,7 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             gm.n_hi = 0;
             hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((skinny_row_reduce_kernel<NB>), dim3((N16 + 3) / 4), dim3(256), 0, s, a, gm);
+            hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);
             return hipGetLastError();
         }
     }
