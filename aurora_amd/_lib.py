@@ -94,6 +94,11 @@ def lib():
             raise AuroraHipError(
                 f"{SO_PATH} is missing: build it with `python -m aurora_amd.build` (hipcc --offload-arch=gfx950). "
                 "aurora_amd has no CPU fallback.")
+        # One HIP runtime per process: torch ships its own libamdhip64 and owns the device memory and streams this
+        # library is handed, so it must be resident before the .so resolves its libamdhip64 dependency. Loaded the other
+        # way round the .so binds /opt/rocm's copy, torch then brings a second runtime, and the first kernel-attribute
+        # call in aur_create reports "no ROCm-capable device".
+        import torch  # noqa: F401
         l = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the .so does not export it

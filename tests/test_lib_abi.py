@@ -77,3 +77,20 @@ def test_llama_row_map_is_a_permutation_with_rope_pairs():
             a = rm[h * hd + 32 * p: h * hd + 32 * p + 16]
             b = rm[h * hd + 32 * p + 16: h * hd + 32 * p + 32]
             assert (b - a == hd // 2).all() and (a == h * hd + 16 * p + np.arange(16)).all()
+
+
+def test_loader_brings_torch_hip_runtime_first():
+    """`__graft_entry__.build()` loads the library in a process that has not imported torch yet. The loader must make
+    torch (and with it torch's libamdhip64) resident first, otherwise the process ends up with two HIP runtimes and the
+    first `aur_create` on a GPU box fails with "no ROCm-capable device"."""
+    import subprocess
+    import sys
+    code = ("import sys; from aurora_amd import _lib; assert 'torch' not in sys.modules; _lib.lib(); "
+            "assert 'torch' in sys.modules; "
+            "maps = open('/proc/self/maps').read(); "
+            "hips = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}; "
+            "assert len(hips) == 1, hips; print(sorted(hips)[0])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "torch" in out.stdout, out.stdout
