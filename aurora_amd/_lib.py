@@ -25,6 +25,7 @@ class AurConfig(C.Structure):
         ("llm_rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_factor", C.c_float),
         ("max_frames", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32),
         ("page_tokens", C.c_int32), ("use_graph", C.c_int32), ("num_banks", C.c_int32), ("vit_native_image", C.c_int32),
+        ("spare_slots", C.c_int32),
     ]
 
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "aur_select_bank": (C.c_int, [_P, _I]),
     "aur_llm_prefill": (C.c_int, [_P, _I, _P, _I, _P]),
     "aur_llm_prefill_batch": (C.c_int, [_P, _I, _I, _P, _I, _P]),
+    "aur_llm_prefill_stage": (C.c_int, [_P, _I, _I, _P, _I, _P]),
+    "aur_llm_prefill_commit": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "aur_llm_decode": (C.c_int, [_P, _I, _P]),
     "aur_get_outputs": (C.c_int, [_P, _IP, _IP, _P]),
     "aur_unfinished": (C.c_int, [_P, _IP, _P]),

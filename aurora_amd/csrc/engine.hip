@@ -51,6 +51,7 @@ struct aur_ctx {
     // derived: llm
     int l_hd, l_kblk, l_vd16, l_qkv_npad, l_gu_npad, l_dpad, l_vocab_pad, l_max_pages, l_ctx_pad;
     int64_t l_page_halves, l_layer_halves;
+    int kv_seqs = 0;                 // KV sequences per bank (max_batch decode slots + cfg.spare_slots)
     // weights
     std::vector<VitLayerW> vl;
     std::vector<LlmLayerW> ll;
@@ -66,6 +67,7 @@ struct aur_ctx {
     float *d_logits, *d_part_o, *d_part_ml;
     float2* l_rope;
     int32_t *s_pos, *s_ids, *s_len, *s_fin, *s_ptab;
+    int32_t* ptab_rw() { return const_cast<int32_t*>(ptab_cur); }
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
@@ -189,7 +191,8 @@ static void derive(aur_ctx* c) {
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
     c->nbanks = g.num_banks == 2 ? 2 : 1;
     c->skinny_variant = g.max_batch > 32 ? 1 : 0;        // a function of the engine's capacity, never of the live batch
-    c->l_layer_halves = c->l_page_halves * c->l_max_pages * g.max_batch * c->nbanks;
+    c->kv_seqs = g.max_batch + (g.spare_slots > 0 ? g.spare_slots : 0);     // KV sequences per bank: decode slots + spare prefill targets
+    c->l_layer_halves = c->l_page_halves * c->l_max_pages * c->kv_seqs * c->nbanks;
     // decode attention: one wave per (sequence, head, split).  Enough splits to put ~512 waves on the GPU for small batches,
     // as few as possible (1) once the batch supplies them - every extra split re-reads q, writes a partial and lengthens
     // the combine (measured at a 2.2k context: B=64 344 us with 2 splits vs 362 with 10; B=1 15.1 us with 13 vs 24.8 with 38).
@@ -254,8 +257,8 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
-    c->s_ptab = k.take<int32_t>(2 * B * c->l_max_pages);
-    for (int bk = 0; bk < 2; ++bk) c->banks[bk].ptab = c->s_ptab ? c->s_ptab + (int64_t)bk * B * c->l_max_pages : nullptr;
+    c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
+    for (int bk = 0; bk < 2; ++bk) c->banks[bk].ptab = c->s_ptab ? c->s_ptab + (int64_t)bk * c->kv_seqs * c->l_max_pages : nullptr;
     {   // alias the current bank
         const aur_ctx::Bank& K = c->banks[c->cur_bank];
         c->d_x = K.d_x; c->s_ssq_mlp = K.s_ssq_mlp; c->s_ssq_attn = K.s_ssq_attn; c->d_logits = K.d_logits;
@@ -409,8 +412,8 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
                 tab[(size_t)p * half + i] = make_float2(cosf(ang), sinf(ang));
             }
         CK(hipMemcpyAsync(ctx->l_rope, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, s));
-        std::vector<int32_t> pt((size_t)2 * g.max_batch * ctx->l_max_pages);
-        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;      // static allocation: slot b owns pages [b*max_pages, ...)
+        std::vector<int32_t> pt((size_t)2 * ctx->kv_seqs * ctx->l_max_pages);
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;      // initial allocation: sequence q owns pages [q*max_pages, ...)
         CK(hipMemcpyAsync(ctx->s_ptab, pt.data(), pt.size() * 4, hipMemcpyHostToDevice, s));
         // decode scratch in x-fragment form: lanes of unused batch rows must hold finite values forever
         CK(hipMemsetAsync(ctx->d_attn, 0, (size_t)rup(g.max_batch, 16) * g.llm_hidden * 2, s));
@@ -862,27 +865,74 @@ static int prefill_layer(aur_ctx* ctx, int l, int which, int slot, int nseq, hal
     return AUR_OK;
 }
 
-extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
-    if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_prefill: language weights not finalized");
+// The layer stack of a prefill pass over KV sequences [seq0, seq0 + nseq): KV pages and front-end scratch only - no decode state.
+static int prefill_layers(aur_ctx* ctx, int seq0, int nseq, void* embeds, int seq_len, hipStream_t s, const char* who) {
+    if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "%s: language weights not finalized", who);
     const aur_config& g = ctx->cfg;
-    if (nseq < 1 || slot0 < 0 || slot0 + nseq > ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "slots [%d, %d) outside the batch of %d (aur_begin_batch)", slot0, slot0 + nseq, ctx->batch);
+    if (ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "%s: no active batch (aur_begin_batch)", who);
     if (seq_len < 1 || seq_len + ctx->max_new > g.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, g.max_ctx);
-    hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "prefill", s);
-    const int d = g.llm_hidden, Mseq = rup(seq_len, 32);
-    half_t* x = (half_t*)embeds;
     ctx->last_prefill_len = seq_len;
     for (int l = 0; l < g.llm_layers; ++l) {
-        int rc = prefill_layer(ctx, l, 0x7f, slot0, nseq, x, seq_len, s);
+        int rc = prefill_layer(ctx, l, 0x7f, seq0, nseq, (half_t*)embeds, seq_len, s);
         if (rc) return rc;
     }
-    // logits of each sequence's last prompt position -> first generated tokens
-    // last prompt rows -> residual fragments + sum(x^2): the lm_head applies the (folded) final RMSNorm itself
-    CK(launch_xfrag_norm(x + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
+    return AUR_OK;
+}
+// First tokens of slots [slot0, slot0 + nseq) from the last prompt rows of `embeds` (the final hidden states `prefill_layers` left
+// there): residual fragments + sum(x^2) - the lm_head applies the (folded) final RMSNorm itself -, logits, argmax, bookkeeping.
+static int prefill_first_tokens(aur_ctx* ctx, int slot0, int nseq, void* embeds, int seq_len, hipStream_t s) {
+    const aur_config& g = ctx->cfg;
+    const int d = g.llm_hidden, Mseq = rup(seq_len, 32);
+    CK(launch_xfrag_norm((half_t*)embeds + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
     int rc = lm_head_and_advance(ctx, slot0, nseq, 0, seq_len, s);
     if (rc) return rc;
     stage_end(ctx, "prefill", s);
     return AUR_OK;
+}
+
+extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
+    if (nseq < 1 || slot0 < 0 || slot0 + nseq > ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "slots [%d, %d) outside the batch of %d (aur_begin_batch)", slot0, slot0 + nseq, ctx->batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = prefill_layers(ctx, slot0, nseq, embeds, seq_len, s, "aur_llm_prefill")) return rc;
+    return prefill_first_tokens(ctx, slot0, nseq, embeds, seq_len, s);
+}
+
+extern "C" int aur_llm_prefill_stage(aur_ctx* ctx, int32_t seq0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
+    if (nseq < 1 || seq0 < 0 || seq0 + nseq > ctx->kv_seqs)
+        return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_stage: KV sequences [%d, %d) outside [0, %d) (max_batch + spare_slots)", seq0, seq0 + nseq, ctx->kv_seqs);
+    return prefill_layers(ctx, seq0, nseq, embeds, seq_len, (hipStream_t)stream, "aur_llm_prefill_stage");
+}
+
+// page-table rows of sequences [a0, a0 + n) <-> [b0, b0 + n)
+__global__ void ptab_swap_kernel(int32_t* __restrict__ pt, int a0, int b0, int n, int max_pages) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * max_pages) return;
+    const int j = i / max_pages, p = i - j * max_pages;
+    int32_t* pa = pt + (int64_t)(a0 + j) * max_pages + p;
+    int32_t* pb = pt + (int64_t)(b0 + j) * max_pages + p;
+    const int32_t t = *pa;
+    *pa = *pb;
+    *pb = t;
+}
+
+extern "C" int aur_llm_prefill_commit(aur_ctx* ctx, int32_t slot0, int32_t nseq, int32_t seq0, void* embeds, int32_t seq_len, void* stream) {
+    if (!ctx->finalized || ctx->ll.empty() || ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_prefill_commit: no active batch");
+    if (nseq < 1 || slot0 < 0 || slot0 + nseq > ctx->batch) return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_commit: slots [%d, %d) outside the batch of %d", slot0, slot0 + nseq, ctx->batch);
+    if (seq0 < 0 || seq0 + nseq > ctx->kv_seqs) return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_commit: KV sequences [%d, %d) outside [0, %d)", seq0, seq0 + nseq, ctx->kv_seqs);
+    if (seq0 != slot0 && seq0 < slot0 + nseq && slot0 < seq0 + nseq) return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_commit: slot and sequence ranges overlap");
+    if (seq_len < 1 || seq_len + ctx->max_new > ctx->cfg.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, ctx->cfg.max_ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (seq0 != slot0) {
+        const int n = nseq * ctx->l_max_pages;
+        hipLaunchKernelGGL(ptab_swap_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->ptab_rw(), slot0, seq0, nseq, ctx->l_max_pages);
+        CK(hipGetLastError());
+    }
+    CK(hipMemsetAsync(ctx->s_len + slot0, 0, (size_t)nseq * 4, s));
+    CK(hipMemsetAsync(ctx->s_fin + slot0, 0, (size_t)nseq * 4, s));
+    CK(hipMemsetAsync(ctx->s_pos + slot0, 0, (size_t)nseq * 4, s));
+    CK(hipMemsetAsync(ctx->s_ids + (int64_t)slot0 * ctx->max_new, 0, (size_t)nseq * ctx->max_new * 4, s));
+    return prefill_first_tokens(ctx, slot0, nseq, embeds, seq_len, s);
 }
 extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
     return aur_llm_prefill_batch(ctx, slot, 1, embeds, seq_len, stream);

@@ -38,7 +38,7 @@ def tokens_at_layer(t0: int, r: int, layer: int) -> int:
 class AuroraCapEngine:
     def __init__(self, cfg: dict, weights: dict, *, max_frames: int = 8, max_batch: int = 1, max_ctx: int = 4096,
                  max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, num_banks: int = 1,
-                 max_image: Optional[int] = None, device: str = "cuda:0"):
+                 max_image: Optional[int] = None, device: str = "cuda:0", spare_slots: int = 0):
         if not torch.cuda.is_available():
             raise _lib.AuroraHipError("AuroraCapEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback")
@@ -78,6 +78,8 @@ class AuroraCapEngine:
         c.max_frames, c.max_batch, c.max_ctx = max_frames, max_batch, max_ctx
         c.max_new_tokens, c.page_tokens, c.use_graph = max_new_tokens, page_tokens, int(use_graph)
         c.num_banks = num_banks
+        c.spare_slots = spare_slots
+        self.spare_slots = spare_slots
         self._bank_state = {0: (0, 0), 1: (0, 0)}        # bank -> (batch, max_new) for outputs()
         self._bank = 0
         self.c = c
@@ -379,6 +381,18 @@ class AuroraCapEngine:
         """embeds [nseq * round_up(seq_len, 32), d]: equal-length sequences prefetched in ONE pass (large-M GEMMs)."""
         check(self.ctx, self.L.aur_llm_prefill_batch(self.ctx, slot0, nseq, embeds.data_ptr(), seq_len, self._stream()),
               "aur_llm_prefill_batch")
+
+    def prefill_stage(self, seq0: int, nseq: int, embeds: torch.Tensor, seq_len: int):
+        """The layer stack of `prefill_batch` into KV sequences [seq0, seq0 + nseq) (normally the spare ones,
+        `max_batch ..`): touches no decode state, so it may run on another stream while `decode` runs."""
+        check(self.ctx, self.L.aur_llm_prefill_stage(self.ctx, seq0, nseq, embeds.data_ptr(), seq_len, self._stream()),
+              "aur_llm_prefill_stage")
+
+    def prefill_commit(self, slot0: int, nseq: int, seq0: int, embeds: torch.Tensor, seq_len: int):
+        """On the decode stream, after `prefill_stage` has completed: slots [slot0 ..) take over the pages of sequences
+        [seq0 ..) (which get the slots' old pages), are reset, and receive their first tokens."""
+        check(self.ctx, self.L.aur_llm_prefill_commit(self.ctx, slot0, nseq, seq0, embeds.data_ptr(), seq_len, self._stream()),
+              "aur_llm_prefill_commit")
 
     def decode(self, steps: int):
         check(self.ctx, self.L.aur_llm_decode(self.ctx, steps, self._stream()), "aur_llm_decode")

@@ -1,0 +1,51 @@
+"""HIP streams restricted to a subset of the compute units (`hipExtStreamCreateWithCUMask`).
+
+Why: the decode step is HBM-bound and the front end (ViT + prefill GEMMs) is MFMA-bound.  Measured on MI355X
+(`tools/cumask/cumask_probe.hip`): a streaming read reaches 7.13 TB/s on all 256 CUs and still 6.25 TB/s on 128 of them,
+so an HBM-bound kernel gives up little when it leaves half of the CUs to a concurrent MFMA-bound kernel.
+
+How the mask maps (same probe): the driver deals the mask bits round-robin over the 8 XCDs - bit i is CU (i // 8) of XCD
+(i % 8) - and an XCD whose share of the mask is empty gets ALL its CUs back (workgroups are dealt to every XCD whatever the
+mask says).  A stream can therefore be restricted to "k CUs of every XCD", never to whole XCDs.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_hip = None
+
+
+def _runtime():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # torch's copy: one runtime per process
+        _hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+        _hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    return _hip
+
+
+def cu_mask_words(cus_per_xcd: int, from_top: bool = False, xcds: int = 8, cus_in_xcd: int = 32):
+    """Mask words enabling `cus_per_xcd` CUs of every XCD: the lowest-numbered ones, or the highest with from_top."""
+    if not 1 <= cus_per_xcd <= cus_in_xcd:
+        raise ValueError(f"cus_per_xcd must be in [1, {cus_in_xcd}], got {cus_per_xcd}")
+    nbits = xcds * cus_in_xcd
+    words = [0] * ((nbits + 31) // 32)
+    for i in range(nbits):
+        cu = i // xcds
+        if (cu >= cus_in_xcd - cus_per_xcd) if from_top else (cu < cus_per_xcd):
+            words[i >> 5] |= 1 << (i & 31)
+    return words
+
+
+def cu_masked_stream(cus_per_xcd: int, from_top: bool = False, device=None) -> "torch.cuda.ExternalStream":
+    """A new HIP stream whose kernels run on `cus_per_xcd` CUs of every XCD only (it lives as long as the process)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    words = cu_mask_words(cus_per_xcd, from_top)
+    arr = (C.c_uint32 * len(words))(*words)
+    st = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = _runtime().hipExtStreamCreateWithCUMask(C.byref(st), len(words), arr)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with status {rc}")
+    return torch.cuda.ExternalStream(st.value, device=dev)

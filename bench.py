@@ -50,6 +50,16 @@ def parse():
     p.add_argument("--pipeline", action="store_true",
                    help="overlap batch i's decode with batch i+1's ViT + prefill on two streams / two KV banks "
                         "(measured on MI355X: +2-3 %% captions/s, +37 %% p50 TTFT - off by default)")
+    p.add_argument("--overlap", type=int, default=0, choices=[0, 1],
+                   help="continuous mode: 1 = a group's next front end (ViT + splice + staged prefill into spare KV sequences) runs on its own "
+                        "CU-masked stream WHILE all slots decode, and is committed at the group's boundary; 0 = front ends between decode chunks")
+    p.add_argument("--overlap-steps", type=int, default=12,
+                   help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked)")
+    p.add_argument("--front-cus", type=int, default=0,
+                   help="--overlap 1 / --pipeline: run the front-end stream on this many CUs of every XCD (hipExtStreamCreateWithCUMask; "
+                        "--overlap 1 defaults to 16)")
+    p.add_argument("--decode-cus", type=int, default=0,
+                   help="with --pipeline: run the decode stream on this many CUs of every XCD (taken from the other end)")
     p.add_argument("--gemm-cus", type=int, default=0,
                    help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
                         "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
@@ -229,8 +239,9 @@ def main():
     max_ctx = _rup(L0 + N, 64)
     G = max(1, min(args.prefill_group, B))
     VC = B if args.vit_chunk <= 0 else max(G, args.vit_chunk // G * G)       # clips per ViT pass: a multiple of G
+    overlap = bool(args.overlap) and not (args.batch_mode or pipe or args.decode_chunk > 0)
     eng = AuroraCapEngine(cfg, weights, max_frames=max(VC, G) * F, max_batch=B, max_ctx=max_ctx, max_new_tokens=N,
-                          use_graph=not args.no_graph, num_banks=2 if pipe else 1, device=dev)
+                          use_graph=not args.no_graph, num_banks=2 if pipe else 1, device=dev, spare_slots=G if overlap else 0)
     del weights
     torch.cuda.empty_cache()
     if args.gemm_mode >= 0:
@@ -354,7 +365,65 @@ def main():
             return o
 
         cycle(True, False)                                         # fill: the groups enter one after another (untimed set-up)
-        for _ in range(max(args.warmup - 1, 0)):
+        if overlap:
+            # ---- the front end of a group's NEXT clips runs on its own stream, restricted to `fc` CUs of every XCD, while all B
+            #      slots keep decoding (HBM-bound decode next to MFMA-bound ViT / prefill): aur_llm_prefill_stage writes spare KV
+            #      sequences B .. B + G - 1, and at the group's boundary aur_llm_prefill_commit (decode stream) exchanges page-table
+            #      rows and produces the first tokens.  The first `overlap_steps` decode steps of a chunk run on the complementary
+            #      mask (the front end is in flight), the rest unmasked.
+            from aurora_amd.streams import cu_masked_stream
+            fc = args.front_cus if args.front_cus > 0 else 16
+            sD = torch.cuda.current_stream()
+            sF = cu_masked_stream(fc, device=dev)
+            sDm = cu_masked_stream(32 - fc, from_top=True, device=dev) if args.overlap_steps > 0 else None
+            if args.gemm_cus <= 0:
+                eng.set_option("gemm_max_wgs", 8 * fc)
+            pending = [None]
+
+            def front_async(g):
+                with torch.cuda.stream(sF):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(sF)
+                    vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
+                    for j in range(G):
+                        eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+                    eng.prefill_stage(B, G, emb_all, L0)
+                    evf = torch.cuda.Event()
+                    evf.record(sF)
+                return e0, evf
+
+            def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
+                for g in range(NG):
+                    eng.slot_collect(g * G, G, ids_out[g], len_out[g])
+                    e0, evf = pending[0]
+                    sD.wait_event(evf)
+                    eng.prefill_commit(g * G, G, B, emb_all, L0)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(sD)
+                    if timed:
+                        lat_ev.append((e0, e1))
+                    sF.wait_event(e1)
+                    pending[0] = front_async((g + 1) % NG)
+                    n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
+                    k1 = min(n, args.overlap_steps) if sDm is not None else 0
+                    if k1 > 0:
+                        sDm.wait_event(e1)
+                        with torch.cuda.stream(sDm):
+                            eng.decode(k1)
+                            evm = torch.cuda.Event()
+                            evm.record(sDm)
+                        sD.wait_event(evm)
+                    if n - k1 > 0:
+                        eng.decode(n - k1)
+                got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
+                o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
+                if world > 1:
+                    parallel.gather_results(o, N, B, cdev)
+                return o
+
+            sF.wait_stream(sD)
+            pending[0] = front_async(0)
+        for _ in range(max(args.warmup - 1, 1 if overlap else 0)):  # overlap: the first front end above overlapped nothing
             cycle(False, False)
         fence()
         t_start = time.perf_counter()
@@ -383,6 +452,17 @@ def main():
     else:
         sD = torch.cuda.current_stream()                           # the engine's stream: decode
         sP = torch.cuda.Stream()                                   # front end of the next batch
+        if args.front_cus > 0 or args.decode_cus > 0:
+            from aurora_amd.streams import cu_masked_stream
+            if args.front_cus > 0:
+                sP = cu_masked_stream(args.front_cus, device=dev)
+                if args.gemm_cus <= 0:
+                    eng.set_option("gemm_max_wgs", 8 * args.front_cus)
+            if args.decode_cus > 0:
+                sDm = cu_masked_stream(args.decode_cus, from_top=True, device=dev)
+                sDm.wait_stream(sD)
+                torch.cuda.set_stream(sDm)
+                sD = sDm
         sP.wait_stream(sD)
         ev_front = [None, None]
         ev_back = [None, None]
@@ -445,7 +525,11 @@ def main():
                        "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G, "vit_chunk": G if continuous else VC,
                        "mode": ("continuous batching, steady state: %d KV slots always decoding; groups of %d clips are collected and re-filled "
                                 "(ViT + splice + one prefill pass) every %d decode steps; one step = one cycle of %d decode steps = %d captions "
-                                "completed + %d front ends" % (B, G, S // NG, S, B, B)) if continuous else "batch: front end of all clips, then B-wide decode",
+                                "completed + %d front ends" % (B, G, S // NG, S, B, B)
+                                + ("; the front ends run on their own stream on %d CUs of every XCD while all slots decode (staged prefill into "
+                                   "spare KV sequences, committed at the group's boundary; %d decode steps per chunk on the other %d CUs per XCD)"
+                                   % (args.front_cus if args.front_cus > 0 else 16, args.overlap_steps, 32 - (args.front_cus if args.front_cus > 0 else 16))
+                                   if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "

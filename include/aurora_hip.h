@@ -47,7 +47,7 @@ typedef struct aur_config {
     float llm_rms_eps, rope_theta, rope_factor;   /* linear RoPE scaling factor (vicuna-16k: 4.0) */
     /* capacity */
     int32_t max_frames;         /* frames per aur_vit_encode call */
-    int32_t max_batch;          /* decode slots (sequences resident in the KV pool), <= 64 */
+    int32_t max_batch;          /* decode slots (batch rows of the decode step), <= 128 */
     int32_t max_ctx;            /* tokens per sequence (prompt + generated) */
     int32_t max_new_tokens;     /* output buffer width per slot */
     int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
@@ -55,6 +55,8 @@ typedef struct aur_config {
     int32_t num_banks;          /* 1 or 2 generation banks (2: KV pool and per-batch state doubled, see aur_select_bank) */
     int32_t vit_native_image;   /* side of the square input the checkpoint's position table was trained for (config.image_size);
                                  * 0 = vit_image.  vit_image is then the CAPACITY: the largest input side aur_vit_encode_hw accepts */
+    int32_t spare_slots;        /* extra KV sequences per bank beyond max_batch (ids max_batch .. max_batch + spare_slots - 1): targets of
+                                 * aur_llm_prefill_stage while every decode slot is still generating.  0 = none */
 } aur_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -125,6 +127,18 @@ int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, v
 /* Same for `nseq` sequences of EQUAL length in slots [slot0, slot0 + nseq): embeds is
  * [nseq * round_up(seq_len,32), llm_hidden]; one pass of M = nseq * round_up(seq_len,32) rows through every GEMM. */
 int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream);
+/* The same prefill in two halves, for a front end that runs on its OWN stream (e.g. a CU-masked one) next to the decode
+ * stream while all slots are still generating (the reference harness has no such overlap: it runs one clip at a time,
+ * lmms_eval/models/auroracap.py:344-525):
+ *   stage : the layer stack only - writes the KV pages of KV sequences [seq0, seq0 + nseq) (any ids below
+ *           max_batch + spare_slots; normally the spare ones) and leaves the final hidden states in `embeds`.  Touches no
+ *           decode state, so it may run concurrently with aur_llm_decode on another stream.
+ *   commit: on the DECODE stream, between two aur_llm_decode calls and after `stage` has completed (caller's event):
+ *           exchanges the page-table rows of slots [slot0 ..) with those of sequences [seq0 ..) - the slots now own the
+ *           freshly written pages, the spare sequences own the pages the slots used before -, resets the slots, and
+ *           produces their first tokens from the last prompt rows of `embeds`.  seq0 == slot0: no exchange. */
+int aur_llm_prefill_stage(aur_ctx* ctx, int32_t seq0, int32_t nseq, void* embeds, int32_t seq_len, void* stream);
+int aur_llm_prefill_commit(aur_ctx* ctx, int32_t slot0, int32_t nseq, int32_t seq0, void* embeds, int32_t seq_len, void* stream);
 /* Run `steps` decode steps for slots [0, batch): one new token per unfinished slot per step. */
 int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream);
 /* Synchronises the stream and copies results to host: ids [batch * max_new_tokens], lens [batch]. */

@@ -134,3 +134,74 @@ def test_prefill_batch_equals_per_slot(name, L):
     finally:
         eng.set_option("gemm_mode", 1)
         eng.close()
+
+
+@pytest.mark.parametrize("use_graph,masked", [(True, False), (False, False), (True, True)])
+def test_staged_prefill_on_a_second_stream_while_all_slots_decode(use_graph, masked):
+    """aur_llm_prefill_stage writes spare KV sequences on a second (optionally CU-masked) stream while every slot keeps
+    decoding; aur_llm_prefill_commit hands the pages to the slots between two decode calls.  The untouched slots must
+    generate exactly what they generate without the interleaved front end, and the re-filled slots exactly what their
+    prompts generate alone - twice over, so that the second round runs on the exchanged page-table rows."""
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.util import rand_llm_weights
+    cfg = LLM_CFGS["hd64"]
+    w = rand_llm_weights(cfg, 17)
+    gen = torch.Generator().manual_seed(51)
+    first = [torch.randn(100, cfg["hidden_size"], generator=gen).half().float() for _ in range(4)]
+    nxt = [torch.randn(120, cfg["hidden_size"], generator=gen).half().float() for _ in range(2)]
+    third = [torch.randn(77, cfg["hidden_size"], generator=gen).half().float() for _ in range(2)]
+    NEW = 40
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=4, max_ctx=512, max_new_tokens=NEW,
+                          use_graph=use_graph, spare_slots=2)
+    try:
+        def big(xs):
+            return torch.cat([padded(e) for e in xs], 0).contiguous()
+        alone = {}
+        for name, xs in (("first", first), ("nxt", nxt), ("third", third)):
+            alone[name] = eng.generate([padded(e) for e in xs], [xs[0].shape[0]] * len(xs), NEW, eos_id=None)
+        sD = torch.cuda.current_stream()
+        if masked:
+            from aurora_amd.streams import cu_masked_stream
+            sF = cu_masked_stream(12)
+        else:
+            sF = torch.cuda.Stream()
+        eng.begin_batch(4, NEW, None)
+        eng.prefill_batch(0, 4, big(first), 100)
+        eng.decode(7)                                               # every slot has 8 tokens
+        # front end for slots 1, 2 into the spare sequences 4, 5 - concurrently with 9 more decode steps of ALL slots
+        emb2 = big(nxt)
+        sF.wait_stream(sD)
+        with torch.cuda.stream(sF):
+            eng.prefill_stage(4, 2, emb2, 120)
+            ev = torch.cuda.Event()
+            ev.record(sF)
+        eng.decode(9)                                               # 17 tokens
+        sD.wait_event(ev)
+        eng.prefill_commit(1, 2, 4, emb2, 120)                      # slots 1, 2 restart with 1 token each
+        evc = torch.cuda.Event()
+        evc.record(sD)
+        # second round: slots 2, 3 <- `third`, staged into sequences 4, 5 again (they now own the old pages of slots 1, 2)
+        emb3 = big(third)
+        sF.wait_event(evc)
+        with torch.cuda.stream(sF):
+            eng.prefill_stage(4, 2, emb3, 77)
+            ev2 = torch.cuda.Event()
+            ev2.record(sF)
+        eng.decode(10)                                              # slot 0: 27 tokens, slots 1, 2: 11 tokens, slot 3: 27
+        out_mid = eng.outputs()
+        sD.wait_event(ev2)
+        eng.prefill_commit(2, 2, 4, emb3, 77)
+        eng.decode(12)                                              # slot 0: 39, slot 1: 23, slots 2, 3: 13
+        out = eng.outputs()
+        assert out_mid[0] == alone["first"][0][:27] and out_mid[3] == alone["first"][3][:27]
+        assert out_mid[1] == alone["nxt"][0][:11] and out_mid[2] == alone["nxt"][1][:11]
+        assert out[0] == alone["first"][0][:39]
+        assert out[1] == alone["nxt"][0][:23]
+        assert out[2] == alone["third"][0][:13] and out[3] == alone["third"][1][:13]
+        from aurora_amd._lib import AuroraHipError
+        with pytest.raises(AuroraHipError):
+            eng.prefill_stage(5, 2, emb3, 77)                       # sequences [5, 7) exceed max_batch + spare_slots
+        with pytest.raises(AuroraHipError):
+            eng.prefill_commit(3, 2, 4, emb3, 77)                   # slots [3, 5) exceed the batch
+    finally:
+        eng.close()

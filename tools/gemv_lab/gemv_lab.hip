@@ -52,10 +52,10 @@ __global__ void fill_kernel(half_t* p, size_t n, uint32_t seed, float scale) {
 }
 
 // naive reference straight from the fragment layouts: out_ll[tile][nb][lane][i] = y[n = tile*16 + 4g + i][b = nb*16 + c]
-__global__ void ref_kernel(const half_t* W, const half_t* xf, float* out, int N16, int K32) {
+__global__ void ref_kernel(const half_t* W, const half_t* xf, float* out, int N16, int K32, int NB) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (tile, nb, lane, i)
-    if (id >= (int64_t)N16 * 4 * 64 * 4) return;
-    const int i = id & 3, lane = (id >> 2) & 63, nb = (id >> 8) & 3, tile = id >> 10;
+    if (id >= (int64_t)N16 * NB * 64 * 4) return;
+    const int i = id & 3, lane = (id >> 2) & 63, nb = (int)((id >> 8) % NB), tile = (int)((id >> 8) / NB);
     const int g = lane >> 4, c = lane & 15;
     const int r = 4 * g + i;
     float s = 0.f;
@@ -172,10 +172,11 @@ __global__ __launch_bounds__(64 * NW) void cur_kernel(Args a) {
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int T_MAX, int KS, int KC, int NBUF, int U, int ROT, int NL>
+template <int T_MAX, int KS, int KC, int NBUF, int U, int ROT, int NL, int NB, int LM>
 __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skx_kernel(Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x 4 KiB
-    constexpr int NB = 4, NCW = T_MAX * KS, Q = KC / KS;                // Q steps per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB
+    constexpr int NCW = T_MAX * KS, Q = KC / KS;                        // Q steps per wave per chunk
+    constexpr int CHUNK = KC * NB * 1024, LB = LM == 1 ? 2 : NBUF;           // LDS ring depth
     constexpr int PIECES = KC * NB / NL;                                // DMA instructions per chunk per loader wave
     static_assert((KC * NB) % NL == 0, "pieces per chunk must split evenly over the loader waves");
     static_assert(KC % KS == 0 && (Q % U == 0 || U % Q == 0), "chunk steps per wave vs pipeline depth");
@@ -190,14 +191,47 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skx_kernel(Args a) {
     const int rot = ROT ? (int)((c * 3u + s) % (unsigned)nchunk) : 0;
     auto chunk_of = [&](int ci) { int x = ci + rot; return x >= nchunk ? x - nchunk : x; };
 
+    if (w >= NCW && LM == 1) {                                 // ---------------- loader waves, register staged: global_load -> ds_write
+        // R chunks in flight in VGPRs (R x PIECES x 4 registers), the LDS ring only double-buffers (any NBUF >= 2)
+        constexpr int R = NBUF - 1;
+        const int lw = w - NCW;
+        h8 rg[R][PIECES];
+        auto src = [&](int ci, int q) {
+            const int piece = q * NL + lw, kk = piece / NB, nb = piece % NB;
+            int kr = chunk_of(ci < nchunk ? ci : nchunk - 1) * KC + kk;
+            kr = kr < KE ? kr : KE - 1;
+            return (const h8*)(a.xf + ((int64_t)nb * K32 + kb + kr) * FRAG + lane * 8);
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) rg[r][q] = *src(r, q);
+        for (int c0 = 0; c0 < nchunk; c0 += R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int ci = c0 + r;
+                if (ci < nchunk) {
+                    wait_vm<(R - 1) * PIECES>();
+                    char* buf = smem + (ci % LB) * CHUNK + lane * 16;
+#pragma unroll
+                    for (int q = 0; q < PIECES; ++q) *(h8*)(buf + (q * NL + lw) * 1024) = rg[r][q];
+#pragma unroll
+                    for (int q = 0; q < PIECES; ++q) rg[r][q] = *src(ci + R, q);        // always issued: the vmcnt above counts them
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    BAR();
+                }
+            }
+        }
+        return;
+    }
     if (w >= NCW) {                                            // ---------------- loader waves (piece q of a chunk -> loader q % NL)
         const int lw = w - NCW;
         auto issue = [&](int ci) {
             const int ch = chunk_of(ci);
-            char* buf = smem + (ci % NBUF) * (KC * 4096);
+            char* buf = smem + (ci % LB) * CHUNK;
 #pragma unroll
             for (int q = 0; q < PIECES; ++q) {
-                const int piece = q * NL + lw, kk = piece >> 2, nb = piece & 3;
+                const int piece = q * NL + lw, kk = piece / NB, nb = piece % NB;
                 int kr = ch * KC + kk;
                 kr = kr < KE ? kr : KE - 1;                    // always PIECES instructions per chunk: the vmcnt below counts them
                 glds16(a.xf + ((int64_t)nb * K32 + kb + kr) * FRAG + lane * 8, buf + piece * 1024);
@@ -255,12 +289,12 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skx_kernel(Args a) {
             const int j = j0 + u;
             if (j < NS && j % Q == 0) BAR();                   // chunk j / Q landed (and chunk j / Q - 1 is released)
             const int ci = j / Q, kk = (j % Q) * KS + p;
-            const char* buf = smem + (ci % NBUF) * (KC * 4096) + lane * 16;
+            const char* buf = smem + (ci % LB) * CHUNK + lane * 16;
             bool valid;
             (void)kof(j, valid);
             h8 xr[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) xr[nb] = *(const h8*)(buf + (kk * 4 + nb) * 1024);
+            for (int nb = 0; nb < NB; ++nb) xr[nb] = *(const h8*)(buf + (kk * NB + nb) * 1024);
             if (!valid) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) xr[nb] = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -341,20 +375,19 @@ struct Shape {
     int N16, K32, copies;
 };
 
-template <int T_MAX, int KS, int KC, int NBUF, int U, int ROT, int NL = 1>
+template <int T_MAX, int KS, int KC, int NBUF, int U, int ROT, int NL = 1, int NB = 4, int LM = 0>
 static void launch_skx(dim3 grid, const Args& a, hipStream_t st) {
-    constexpr int lds = NBUF * KC * 4096;
+    constexpr int lds = (LM == 1 ? 2 : NBUF) * KC * NB * 1024 > T_MAX * KS * NB * 1024 ? (LM == 1 ? 2 : NBUF) * KC * NB * 1024 : T_MAX * KS * NB * 1024;
     static bool once = false;
     if (!once) {
-        CKH(hipFuncSetAttribute((const void*)skx_kernel<T_MAX, KS, KC, NBUF, U, ROT, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CKH(hipFuncSetAttribute((const void*)skx_kernel<T_MAX, KS, KC, (LM == 1 ? NBUF : NBUF), U, ROT, NL, NB, LM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once = true;
     }
-    hipLaunchKernelGGL((skx_kernel<T_MAX, KS, KC, NBUF, U, ROT, NL>), grid, dim3(64 * (T_MAX * KS + NL)), lds, st, a);
+    hipLaunchKernelGGL((skx_kernel<T_MAX, KS, KC, NBUF, U, ROT, NL, NB, LM>), grid, dim3(64 * (T_MAX * KS + NL)), lds, st, a);
 }
 
-int main(int argc, char** argv) {
-    const int iters = argc > 1 ? atoi(argv[1]) : 96;
-    const char* only = argc > 2 ? argv[2] : "";
+template <int NB>
+static void lab(int iters, const char* only) {
     hipStream_t st;
     CKH(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -369,14 +402,14 @@ int main(int argc, char** argv) {
         half_t* xf;
         float *out, *ref, *part;
         CKH(hipMalloc(&W, (size_t)whalves * 2 * sh.copies));
-        CKH(hipMalloc(&xf, (size_t)4 * sh.K32 * FRAG * 2));
-        const int64_t nout = (int64_t)sh.N16 * 4 * 64 * 4;
+        CKH(hipMalloc(&xf, (size_t)NB * sh.K32 * FRAG * 2));
+        const int64_t nout = (int64_t)sh.N16 * NB * 64 * 4;
         CKH(hipMalloc(&out, nout * 4));
         CKH(hipMalloc(&ref, nout * 4));
         CKH(hipMalloc(&part, nout * 4 * 16));
         fill_kernel<<<2048, 256, 0, st>>>(W, (size_t)whalves * sh.copies, 0x1234u, 0.05f);
-        fill_kernel<<<256, 256, 0, st>>>(xf, (size_t)4 * sh.K32 * FRAG, 0x77u, 1.0f);
-        ref_kernel<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(W, xf, ref, sh.N16, sh.K32);       // copy 0
+        fill_kernel<<<256, 256, 0, st>>>(xf, (size_t)NB * sh.K32 * FRAG, 0x77u, 1.0f);
+        ref_kernel<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(W, xf, ref, sh.N16, sh.K32, NB);       // copy 0
         CKH(hipStreamSynchronize(st));
         std::vector<float> href(nout), hout(nout);
         CKH(hipMemcpy(href.data(), ref, nout * 4, hipMemcpyDeviceToHost));
@@ -428,48 +461,60 @@ int main(int argc, char** argv) {
         // ---- ceiling: pure streaming of the weights (launch to launch, boundary included)
         run("stream U8 (256 wg x 8 waves)", [&](int cp) { stream_kernel<8><<<256, 512, 0, st>>>(W + (int64_t)cp * whalves, wfr, out); }, false, 0);
         run("stream U8 (512 wg x 8 waves)", [&](int cp) { stream_kernel<8><<<512, 512, 0, st>>>(W + (int64_t)cp * whalves, wfr, out); }, false, 0);
-        // ---- A: current structure (+ variants)
-        if (nm == "o" || nm == "down") {
-            run("cur NT1 NW8 U4", [&](int cp) { cur_kernel<1, 8, 4, 0, 0><<<sh.N16, 512, 8 * 1 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, true, 0);
-            run("cur NT1 NW8 U4 noX", [&](int cp) { cur_kernel<1, 8, 4, 1, 0><<<sh.N16, 512, 8 * 1 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, false, 0);
-            if (nm == "o") {
+        // ---- A: per-wave x structure (64 rows only)
+        if constexpr (NB == 4) {
+            if (nm == "o" || nm == "down") {
+                run("cur NT1 NW8 U4", [&](int cp) { cur_kernel<1, 8, 4, 0, 0><<<sh.N16, 512, 8 * 1 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, true, 0);
+                run("cur NT1 NW8 U4 noX", [&](int cp) { cur_kernel<1, 8, 4, 1, 0><<<sh.N16, 512, 8 * 1 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, false, 0);
+            } else {
+                run("cur NT2 NW4 U4", [&](int cp) { cur_kernel<2, 4, 4, 0, 0><<<sh.N16 / 2, 256, 4 * 2 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, true, 0);
+                run("cur NT2 NW4 U4 noX", [&](int cp) { cur_kernel<2, 4, 4, 1, 0><<<sh.N16 / 2, 256, 4 * 2 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, false, 0);
             }
-        } else {
-            run("cur NT2 NW4 U4", [&](int cp) { cur_kernel<2, 4, 4, 0, 0><<<sh.N16 / 2, 256, 4 * 2 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, true, 0);
-            run("cur NT2 NW4 U4 noX", [&](int cp) { cur_kernel<2, 4, 4, 1, 0><<<sh.N16 / 2, 256, 4 * 2 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, false, 0);
-            run("cur NT4 NW4 U4", [&](int cp) { cur_kernel<4, 4, 4, 0, 0><<<sh.N16 / 4, 256, 4 * 4 * 4 * 1024, st>>>(mk(cp, out, 1, 0, 0)); }, true, 0);
         }
-        // ---- B: x through LDS
+        // ---- B: x through LDS.  dma = LDS-DMA loader waves (the shipped structure), reg = global_load -> ds_write loader waves
+        constexpr int KC = NB <= 4 ? 8 : 4;
         auto red = [&](int S) { reduce_kernel<<<(unsigned)((nout / 4 + 255) / 256), 256, 0, st>>>(part, out, nout / 4, S); };
         if (nm == "o" || nm == "down") {
-            run("skx T8 KS1 S8 KC4 NB4 U4 NL4 main only", [&](int cp) { launch_skx<8, 1, 4, 4, 4, 0, 4>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); }, false, 0);
-            run("skx T8 KS1 S8 KC4 NB8 U4 NL4 main only", [&](int cp) { launch_skx<8, 1, 4, 8, 4, 0, 4>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); }, false, 0);
-            run("skx T8 KS1 S8 KC8 NB4 U4 NL4 main only", [&](int cp) { launch_skx<8, 1, 8, 4, 4, 0, 4>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); }, false, 0);
-            run("skx T8 KS1 S8 KC4 NB8 U4 NL4 + reduce", [&](int cp) { launch_skx<8, 1, 4, 8, 4, 0, 4>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); red(8); }, true, 0);
-            run("skx T8 KS1 S8 KC4 NB8 U4 NL8 + reduce", [&](int cp) { launch_skx<8, 1, 4, 8, 4, 0, 8>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); red(8); }, true, 0);
-            run("skx T4 KS3 S4 KC6 NB5 U2 NL4 + reduce", [&](int cp) { launch_skx<4, 3, 6, 5, 2, 0, 4>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
-            run("skx T4 KS2 S4 KC4 NB8 U4 NL4 + reduce", [&](int cp) { launch_skx<4, 2, 4, 8, 4, 0, 4>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
-            run("skx T2 KS4 S2 KC4 NB8 U4 NL4 + reduce", [&](int cp) { launch_skx<2, 4, 4, 8, 4, 0, 4>(dim3(sh.N16 / 2, 2), mk(cp, part, 2, 2, 0), st); red(2); }, true, 0);
-            run("skx T1 KS8 S1 KC8 NB4 U4 NL8", [&](int cp) { launch_skx<1, 8, 8, 4, 4, 0, 8>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
+            constexpr int KCR = NB <= 4 ? 6 : 3, NBUFR = NB <= 4 ? 5 : 4, NLR = NB <= 4 ? 2 : 3;
+            run("skx T4 KS3 S4 dma (shipped) + reduce", [&](int cp) { launch_skx<4, 3, KCR, NBUFR, 2, 0, NLR, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+            run("skx T4 KS3 S4 reg R2 NL2 + reduce", [&](int cp) { launch_skx<4, 3, KCR, 3, 2, 0, (NB <= 4 ? 2 : 3), NB, 1>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+            run("skx T4 KS3 S4 reg R3 NL4 KC6 + reduce", [&](int cp) { launch_skx<4, 3, 6, 4, 2, 0, 4, NB, 1>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+            run("skx T8 KS1 S8 dma NL4 + reduce", [&](int cp) { launch_skx<8, 1, 4, 4, 4, 0, 4, NB, 0>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); red(8); }, true, 0);
+            if constexpr (NB <= 4) run("skx T1 KS8 S1 dma NL8", [&](int cp) { launch_skx<1, 8, 8, 4, 4, 0, 8, NB, 0>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
+            if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL4", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 4, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
+            if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL8", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 8, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
         } else if (nm == "qkv") {
-            run("skx T3 KS4 S1 KC4 NB4 U4 NL4", [&](int cp) { launch_skx<3, 4, 4, 4, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
-            run("skx T3 KS4 S1 KC4 NB8 U4 NL4", [&](int cp) { launch_skx<3, 4, 4, 8, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
-            run("skx T3 KS4 S1 KC8 NB4 U4 NL4", [&](int cp) { launch_skx<3, 4, 8, 4, 2, 0, 4>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
-            run("skx T3 KS2 S1 KC4 NB8 U4 NL4", [&](int cp) { launch_skx<3, 2, 4, 8, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
-            run("skx T3 KS2 S1 KC4 NB8 U8 NL8", [&](int cp) { launch_skx<3, 2, 4, 8, 8, 0, 8>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
-            run("skx T3 KS4 S1 KC4 NB9 U4 NL4", [&](int cp) { launch_skx<3, 4, 4, 9, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T3 KS4 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<3, 4, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T6 KS2 S2 dma NL4 + reduce", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 6, 0), st); red(2); }, true, 0);
+            run("skx T12 KS1 S4 dma NL4 + reduce", [&](int cp) { launch_skx<12, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(64, 4), mk(cp, part, 4, 12, 0), st); red(4); }, true, 0);
+            run("skx T12 KS1 S4 dma NL4 main only", [&](int cp) { launch_skx<12, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(64, 4), mk(cp, part, 4, 12, 0), st); }, false, 0);
+            run("skx T12 KS1 S4 dma NL2 U8 + reduce", [&](int cp) { launch_skx<12, 1, KC, 4, 8, 0, 2, NB, 0>(dim3(64, 4), mk(cp, part, 4, 12, 0), st); red(4); }, true, 0);
+            run("skx T6 KS2 S8 dma NL4 + reduce", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 8), mk(cp, part, 8, 6, 0), st); red(8); }, true, 0);
+            run("skx T3 KS4 reg R2 U4 NL4", [&](int cp) { launch_skx<3, 4, KC, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T3 KS4 reg R3 U4 NL4", [&](int cp) { launch_skx<3, 4, KC, 4, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T3 KS4 reg R2 U4 NL2", [&](int cp) { launch_skx<3, 4, KC, 3, 4, 0, 2, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T3 KS4 reg R2 U4 NL4 KC8", [&](int cp) { launch_skx<3, 4, 8, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
         } else if (nm == "gateup") {
-            run("skx T6 KS2 S1 KC4 NB4 U4 NL4", [&](int cp) { launch_skx<6, 2, 4, 4, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
-            run("skx T6 KS2 S1 KC4 NB8 U4 NL4", [&](int cp) { launch_skx<6, 2, 4, 8, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
-            run("skx T6 KS2 S1 KC8 NB4 U4 NL4", [&](int cp) { launch_skx<6, 2, 8, 4, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
-            run("skx T6 KS2 S1 KC4 NB8 U8 NL4", [&](int cp) { launch_skx<6, 2, 4, 8, 8, 0, 4>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
-            run("skx T6 KS1 S1 KC4 NB8 U4 NL4", [&](int cp) { launch_skx<6, 1, 4, 8, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
-            run("skx T6 KS1 S1 KC4 NB8 U8 NL2", [&](int cp) { launch_skx<6, 1, 4, 8, 8, 0, 2>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T6 KS2 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T11 KS1 S2 dma NL4 + reduce", [&](int cp) { launch_skx<11, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 10, 96), st); red(2); }, true, 0);
+            run("skx T11 KS1 S2 dma NL4 main only", [&](int cp) { launch_skx<11, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 10, 96), st); }, false, 0);
+            run("skx T6 KS2 reg R2 U4 NL4", [&](int cp) { launch_skx<6, 2, KC, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T6 KS2 reg R3 U4 NL4", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T6 KS2 reg R2 U4 NL2", [&](int cp) { launch_skx<6, 2, KC, 3, 4, 0, 2, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T6 KS2 reg R2 U4 NL4 KC8", [&](int cp) { launch_skx<6, 2, 8, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
         } else {
-            run("skx T8 KS1 S1 KC4 NB4 U4 NL4", [&](int cp) { launch_skx<8, 1, 4, 4, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
-            run("skx T8 KS1 S1 KC4 NB8 U4 NL4", [&](int cp) { launch_skx<8, 1, 4, 8, 4, 0, 4>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
+            run("skx T8 KS1 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<8, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
+            run("skx T8 KS1 reg R2 U4 NL4", [&](int cp) { launch_skx<8, 1, KC, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
         }
         CKH(hipFree(W)); CKH(hipFree(xf)); CKH(hipFree(out)); CKH(hipFree(ref)); CKH(hipFree(part));
     }
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 96;
+    const char* only = argc > 2 ? argv[2] : "";
+    const int nb = argc > 3 ? atoi(argv[3]) : 0;            // column groups: 4 (64 rows), 8 (128 rows); 0 = both
+    if (nb == 0 || nb == 4) { printf("---- 64 rows\n"); lab<4>(iters, only); }
+    if (nb == 0 || nb == 8) { printf("---- 128 rows\n"); lab<8>(iters, only); }
     return 0;
 }
