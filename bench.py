@@ -43,18 +43,22 @@ def parse():
     p.add_argument("--num_frm", type=int, default=8)
     p.add_argument("--token_kept_ratio", type=float, default=0.3)
     p.add_argument("--max_new_tokens", type=int, default=256)
-    p.add_argument("--prefill-group", type=int, default=8, help="clips prefetched per prefill pass (equal-length prompts)")
+    p.add_argument("--prefill-group", type=int, default=0,
+                   help="clips per front-end pass = per prefill pass (equal-length prompts); 0 = auto: 4 with --overlap (13.30 captions/s, p50 "
+                        "TTFT 0.30 s; 8: 13.24 / 0.61 s; 2: 12.9 / 0.15 s on one MI355X), 8 otherwise")
     p.add_argument("--vit-chunk", type=int, default=16,
                    help="clips per ViT pass (0 = the whole batch at once); chunks interleave ViT with the prefill groups so the "
                         "first tokens of the early groups come sooner (measured at B=64: 16 -> p50 TTFT -11 %%, captions/s -0.2 %%)")
     p.add_argument("--pipeline", action="store_true",
                    help="overlap batch i's decode with batch i+1's ViT + prefill on two streams / two KV banks "
                         "(measured on MI355X: +2-3 %% captions/s, +37 %% p50 TTFT - off by default)")
-    p.add_argument("--overlap", type=int, default=0, choices=[0, 1],
+    p.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1],
                    help="continuous mode: 1 = a group's next front end (ViT + splice + staged prefill into spare KV sequences) runs on its own "
-                        "CU-masked stream WHILE all slots decode, and is committed at the group's boundary; 0 = front ends between decode chunks")
-    p.add_argument("--overlap-steps", type=int, default=12,
-                   help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked)")
+                        "CU-masked stream WHILE all slots decode, and is committed at the group's boundary; 0 = front ends between decode chunks "
+                        "(11.4 captions/s against 13.2-13.3 with 1 on one MI355X); -1 = auto (1 whenever the continuous mode applies)")
+    p.add_argument("--overlap-steps", type=int, default=-1,
+                   help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
+                        "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
     p.add_argument("--front-cus", type=int, default=0,
                    help="--overlap 1 / --pipeline: run the front-end stream on this many CUs of every XCD (hipExtStreamCreateWithCUMask; "
                         "--overlap 1 defaults to 16)")
@@ -237,9 +241,10 @@ def main():
     n_kept = tokens_at_layer(t0tok, r, v["num_hidden_layers"] - 1) - 1
     L0 = 30 + F * n_kept
     max_ctx = _rup(L0 + N, 64)
-    G = max(1, min(args.prefill_group, B))
+    want_overlap = args.overlap != 0 and not (args.batch_mode or pipe or args.decode_chunk > 0)
+    G = max(1, min(args.prefill_group if args.prefill_group > 0 else (4 if want_overlap else 8), B))
     VC = B if args.vit_chunk <= 0 else max(G, args.vit_chunk // G * G)       # clips per ViT pass: a multiple of G
-    overlap = bool(args.overlap) and not (args.batch_mode or pipe or args.decode_chunk > 0)
+    overlap = want_overlap and B % G == 0 and B // G >= 2 and N >= 2 * (B // G)         # = the continuous mode applies
     eng = AuroraCapEngine(cfg, weights, max_frames=max(VC, G) * F, max_batch=B, max_ctx=max_ctx, max_new_tokens=N,
                           use_graph=not args.no_graph, num_banks=2 if pipe else 1, device=dev, spare_slots=G if overlap else 0)
     del weights
@@ -365,17 +370,38 @@ def main():
             return o
 
         cycle(True, False)                                         # fill: the groups enter one after another (untimed set-up)
+        seq_sched = None
+        masked = None
         if overlap:
+            try:
+                from aurora_amd.streams import cu_masked_stream
+                fc = args.front_cus if args.front_cus > 0 else 16
+                masked = (cu_masked_stream(fc, device=dev), cu_masked_stream(32 - fc, from_top=True, device=dev))
+            except (RuntimeError, OSError, AttributeError) as e:      # no CU-mask support here: keep the sequential schedule
+                print(f"bench.py: CU-masked streams unavailable ({e}); front ends run between decode chunks", file=sys.stderr)
+                overlap = False
+        if overlap:
+            # one cycle of the sequential schedule first (front ends BETWEEN decode chunks on one stream): the latency-oriented
+            # operating point, reported beside the line
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            o_seq = cycle(False, True)
+            torch.cuda.synchronize()
+            seq_ms = 1e3 * (time.perf_counter() - t_s)
+            assert o_seq == batch_ref, "continuous batching (sequential schedule) produced different captions than the batch-mode step"
+            seq_sched = {"captions_per_s": B / (seq_ms / 1e3), "ms_per_step": seq_ms,
+                         "p50_ttft_ms": float(np.median([a.elapsed_time(b) for a, b in lat_ev])),
+                         "note": "one cycle with each group's front end run between two decode chunks on the decode stream (--overlap 0)"}
+            lat_ev.clear()
             # ---- the front end of a group's NEXT clips runs on its own stream, restricted to `fc` CUs of every XCD, while all B
             #      slots keep decoding (HBM-bound decode next to MFMA-bound ViT / prefill): aur_llm_prefill_stage writes spare KV
             #      sequences B .. B + G - 1, and at the group's boundary aur_llm_prefill_commit (decode stream) exchanges page-table
-            #      rows and produces the first tokens.  The first `overlap_steps` decode steps of a chunk run on the complementary
+            #      rows and produces the first tokens.  The first `k_masked` decode steps of a chunk run on the complementary
             #      mask (the front end is in flight), the rest unmasked.
-            from aurora_amd.streams import cu_masked_stream
-            fc = args.front_cus if args.front_cus > 0 else 16
+            k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, int(round(0.8 * (S // NG))))
             sD = torch.cuda.current_stream()
-            sF = cu_masked_stream(fc, device=dev)
-            sDm = cu_masked_stream(32 - fc, from_top=True, device=dev) if args.overlap_steps > 0 else None
+            sF = masked[0]
+            sDm = masked[1] if k_masked > 0 else None
             if args.gemm_cus <= 0:
                 eng.set_option("gemm_max_wgs", 8 * fc)
             pending = [None]
@@ -405,7 +431,7 @@ def main():
                     sF.wait_event(e1)
                     pending[0] = front_async((g + 1) % NG)
                     n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
-                    k1 = min(n, args.overlap_steps) if sDm is not None else 0
+                    k1 = min(n, k_masked) if sDm is not None else 0
                     if k1 > 0:
                         sDm.wait_event(e1)
                         with torch.cuda.stream(sDm):
@@ -435,6 +461,8 @@ def main():
         elapsed = time.perf_counter() - t_start
         # same clips in the same slots as the batch-mode step: batch-invariant kernels must give the same ids, every cycle
         assert all(o == batch_ref for o in outs), "continuous batching produced different captions than the batch-mode step"
+        if overlap and args.gemm_cus <= 0:
+            eng.set_option("gemm_max_wgs", 0)                      # the instrumented pass below runs alone on the whole GPU
         ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
     elif not pipe:
         for _ in range(args.warmup):
@@ -528,16 +556,19 @@ def main():
                                 "completed + %d front ends" % (B, G, S // NG, S, B, B)
                                 + ("; the front ends run on their own stream on %d CUs of every XCD while all slots decode (staged prefill into "
                                    "spare KV sequences, committed at the group's boundary; %d decode steps per chunk on the other %d CUs per XCD)"
-                                   % (args.front_cus if args.front_cus > 0 else 16, args.overlap_steps, 32 - (args.front_cus if args.front_cus > 0 else 16))
-                                   if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
+                                   % (fc, k_masked, 32 - fc) if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "
-                           "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1))
+                           "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1)
+                           + ("; the front end runs on the front-end stream during the chunk before the group's boundary and its first tokens "
+                              "are produced by the commit at that boundary on the decode stream" if overlap else ""))
                           if continuous else
                           "time from the start of a batch's front end to each clip's first token, batch of %d clips (ViT in chunks of %d clips, "
                           "prefill in groups of %d)" % (B, VC, G) + ("; the front end shares the GPU with the previous batch's decode" if pipe else "")),
         }
+        if continuous and overlap:
+            result["sequential_schedule"] = seq_sched
         if continuous:
             result["batch_mode"] = {"captions_per_s": B / (batch_ms / 1e3), "ms_per_step": batch_ms, "p50_ttft_ms": batch_ttft,
                                     "note": "one step of the non-continuous schedule (all %d front ends, then the %d-wide decode), same captions; "

@@ -86,6 +86,14 @@ def test_default_mode_is_steady_state_continuous_batching():
     assert d["config"]["mode"].startswith("continuous batching") and d["value"] > 0 and d["p50_ttft_ms"] > 0
     assert d["batch_mode"]["captions_per_s"] > 0 and d["batch_mode"]["p50_ttft_ms"] > 0
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    # default: the front ends overlap the decode on CU-masked streams (ids verified inside bench.py against the batch-mode step),
+    # with one cycle of the sequential schedule reported beside it
+    assert "own stream" in d["config"]["mode"] and d["sequential_schedule"]["captions_per_s"] > 0
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--prefill-group", "2", "--overlap", "0"] + TINY, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d0 = _json_line(r.stdout)
+    assert d0["config"]["mode"].startswith("continuous batching") and "own stream" not in d0["config"]["mode"] and "sequential_schedule" not in d0
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--prefill-group", "2", "--batch-mode"] + TINY, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and _json_line(r.stdout)["config"]["mode"].startswith("batch")
