@@ -498,17 +498,28 @@ class AuroraCapEngine:
         return lens, fin
 
     def caption_stream(self, clips, token_kept_ratio: float, max_new_tokens: int, eos_id: Optional[int] = 2, slots: Optional[int] = None,
-                       check_every: int = 16, on_error=None):
+                       check_every: int = 16, on_error=None, overlap: Optional[bool] = None, front_cus: int = 16):
         """Continuous batching over an iterable of (pixel_values, input_ids): up to `slots` (default max_batch) captions are
         in flight; every `check_every` decode steps the finished slots are collected and re-filled with the next clips
         (ViT + projector + prefill into the free slot while the others keep their KV and state).  Yields (index, ids) in
         completion order; each clip's ids equal what it produces alone (batch-invariant kernels).
         on_error(index, exception): a clip whose front end is rejected (shape, context longer than max_ctx, ...) is reported
         and skipped while the captions in flight keep going (the reference harness turns a failing request into an empty
-        caption, lmms_eval/models/auroracap.py:511-514); None = raise."""
+        caption, lmms_eval/models/auroracap.py:511-514); None = raise.
+        overlap (default: on when the engine was built with spare_slots > 0): the front ends of the NEXT clips run ahead on
+        their own stream, restricted to `front_cus` CUs of every XCD, into the spare KV sequences while every slot keeps
+        decoding (decode is HBM-bound, ViT + prefill MFMA-bound); a freed slot takes over a prepared clip's pages at the next
+        check (`prefill_commit`).  Same ids either way."""
         B = self.max_batch if slots is None else slots
         if not 1 <= B <= self.max_batch:
             raise ValueError(f"slots={B} for an engine built with max_batch={self.max_batch}")
+        if overlap is None:
+            overlap = self.spare_slots > 0
+        if overlap:
+            if self.spare_slots < 1:
+                raise ValueError("caption_stream(overlap=True) needs an engine built with spare_slots >= 1")
+            yield from self._caption_stream_overlapped(clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus)
+            return
         self.begin_batch(B, max_new_tokens, eos_id)
         for s in range(B):
             self.slot_retire(s)
@@ -544,6 +555,96 @@ class AuroraCapEngine:
                 for s in done:
                     yield owner[s], out[s]
                     owner[s] = None
+
+    def _masked_streams(self, front_cus: int):
+        """(front-end stream on `front_cus` CUs of every XCD, decode stream on the other CUs), created once per engine."""
+        from .streams import cu_masked_stream
+        if not hasattr(self, "_masked"):
+            self._masked = {}
+        if front_cus not in self._masked:
+            self._masked[front_cus] = (cu_masked_stream(front_cus, device=self.dev),
+                                       cu_masked_stream(32 - front_cus, from_top=True, device=self.dev))
+        return self._masked[front_cus]
+
+    def _caption_stream_overlapped(self, clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus):
+        from collections import deque
+        sD = torch.cuda.current_stream(self.dev)
+        sF, sDm = self._masked_streams(front_cus)
+        self.begin_batch(B, max_new_tokens, eos_id)
+        for s in range(B):
+            self.slot_retire(s)
+        it = iter(enumerate(clips))
+        owner: List[Optional[int]] = [None] * B
+        free_seqs = list(range(self.max_batch, self.max_batch + self.spare_slots))     # spare KV sequences holding no prepared clip
+        reusable = {}                                             # sequence -> event after which its (exchanged) pages may be rewritten
+        staged = deque()                                          # prepared clips: (index, sequence, embeds, L, event)
+        exhausted = False
+        sF.wait_stream(sD)
+        self.set_option("gemm_max_wgs", 8 * front_cus)            # the persistent GEMM sizes its grid to the front end's CUs
+        k_masked = max(1, int(round(0.8 * check_every)))
+        try:
+            while True:
+                # 1. slots that are free take over prepared clips (decode stream, between two decode calls)
+                for s in range(B):
+                    if owner[s] is None and staged:
+                        idx, seq, emb, L, ev = staged.popleft()
+                        sD.wait_event(ev)
+                        emb.record_stream(sD)
+                        self.prefill_commit(s, 1, seq, emb, L)
+                        evc = torch.cuda.Event()
+                        evc.record(sD)
+                        reusable[seq] = evc
+                        free_seqs.append(seq)
+                        owner[s] = idx
+                # 2. prepare the next clips into every free spare sequence (front-end stream: runs beside the decode below)
+                enqueued = False
+                while free_seqs and not exhausted:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        exhausted = True
+                        break
+                    idx, (px, ids) = nxt
+                    seq = free_seqs.pop()
+                    try:
+                        with torch.cuda.stream(sF):
+                            if seq in reusable:
+                                sF.wait_event(reusable.pop(seq))
+                            r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
+                            vis = self.vit_encode(px, r)
+                            emb, L = self.project_splice(vis, list(ids))
+                            self.prefill_stage(seq, 1, emb, L)    # argument checks come before any enqueue
+                            ev = torch.cuda.Event()
+                            ev.record(sF)
+                        staged.append((idx, seq, emb, L, ev))
+                        enqueued = True
+                    except (ValueError, IndexError, AssertionError, _lib.AuroraHipError) as e:
+                        free_seqs.append(seq)
+                        if on_error is None:
+                            raise
+                        on_error(idx, e)
+                if all(o is None for o in owner):
+                    if not staged:
+                        return
+                    continue                                      # nothing decoding yet: commit what was just prepared
+                # 3. one decode chunk: while a front end is in flight its first part runs on the complementary CU mask
+                k1 = min(check_every, k_masked) if enqueued else 0
+                if k1 > 0:
+                    sDm.wait_stream(sD)
+                    with torch.cuda.stream(sDm):
+                        self.decode(k1)
+                    sD.wait_stream(sDm)
+                if check_every - k1 > 0:
+                    self.decode(check_every - k1)
+                lens, fin = self.slot_state()
+                done = [s for s in range(B) if owner[s] is not None and fin[s]]
+                if done:
+                    out = self.outputs()
+                    for s in done:
+                        yield owner[s], out[s]
+                        owner[s] = None
+        finally:
+            sD.wait_stream(sF)
+            self.set_option("gemm_max_wgs", 0)
 
     # ------------------------------------------------------------------ kernel-level entry points (tests)
     def tome_step(self, metric: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], r: int):

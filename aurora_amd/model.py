@@ -110,15 +110,17 @@ class AuroraModel:
             out.extend(self.engine.caption_batch(group, self.visual_encoder.visual_token_merge_ratio, n, eos))
         return out
 
-    def caption_stream(self, clips, max_new_tokens: int = 2048, eos_token_id="default", check_every: int = 16, on_error=None):
+    def caption_stream(self, clips, max_new_tokens: int = 2048, eos_token_id="default", check_every: int = 16, on_error=None,
+                       overlap=None):
         """Continuous batching over an iterable of (pixel_values, input_ids): yields (index, new-token ids) as captions
         finish (EOS or max_new_tokens), re-filling freed KV slots with the next clips.  Per-clip results equal the
-        one-at-a-time calls."""
+        one-at-a-time calls.  overlap (default: on for an engine with spare KV sequences): the next clips' front ends run
+        ahead on a CU-masked stream while the slots decode (AuroraCapEngine.caption_stream)."""
         eos = self.llm.eos_token_id if eos_token_id == "default" else eos_token_id
         n = min(max_new_tokens, self.engine.max_new_tokens)
         it = ((px, ids.tolist() if torch.is_tensor(ids) else list(ids)) for px, ids in clips)
         yield from self.engine.caption_stream(it, self.visual_encoder.visual_token_merge_ratio, n, eos, check_every=check_every,
-                                              on_error=on_error)
+                                              on_error=on_error, overlap=overlap)
 
     def __call__(self, data: dict, data_samples=None, mode: str = "loss"):
         return self.forward(data, data_samples, mode)

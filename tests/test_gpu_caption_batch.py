@@ -182,3 +182,36 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
                 assert toks == ids, i
     finally:
         eng.close()
+
+
+def test_caption_stream_with_front_ends_prefetched_beside_the_decode():
+    """An engine with spare KV sequences runs the next clips' front ends ahead on a CU-masked stream while the slots decode
+    (AuroraCapEngine.caption_stream, overlap on by default then): every clip must still get exactly the ids it gets alone -
+    ragged clips, EOS stopping, more clips than slots + spare sequences, a failing request in the middle."""
+    from aurora_amd.engine import AuroraCapEngine
+    eng = AuroraCapEngine({"vit": VCFG, "llm": LLM_CFGS["hd32"]}, weights(), max_frames=4, max_batch=4, max_ctx=512,
+                          max_new_tokens=24, spare_slots=2)
+    try:
+        cs = clips(13, 9)
+        alone_full = [eng.caption_ids(px, ids, 0.5, 24, eos_id=None) for px, ids in cs]
+        eos = alone_full[2][5]
+        want = [a[: a.index(eos) + 1] if eos in a else a for a in alone_full]
+        for check_every in (4, 5, 16):
+            got = dict(eng.caption_stream(cs, 0.5, 24, eos_id=eos, check_every=check_every))
+            assert sorted(got) == list(range(13))
+            for i in range(13):
+                assert got[i] == want[i], (check_every, i)
+        # the plain schedule on the same engine, then the overlapped one again (page-table rows have been exchanged many times by now)
+        got = dict(eng.caption_stream(cs, 0.5, 24, eos_id=eos, check_every=4, overlap=False))
+        assert all(got[i] == want[i] for i in range(13))
+        bad = list(cs)
+        bad[5] = (torch.randn(5, 3, 56, 56).half(), [1] + [-200, 30] * 5)      # more frames than the engine's max_frames: rejected
+        errs = []
+        got = dict(eng.caption_stream(bad, 0.5, 24, eos_id=eos, slots=3, check_every=4, on_error=lambda i, e: errs.append(i)))
+        assert errs == [5] and sorted(got) == [i for i in range(13) if i != 5]
+        assert all(got[i] == want[i] for i in got)
+        assert list(eng.caption_stream([], 0.5, 7)) == []
+        with pytest.raises(ValueError):
+            list(build(2).caption_stream(cs[:2], 0.5, 7, overlap=True))          # no spare sequences
+    finally:
+        eng.close()
