@@ -422,8 +422,17 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + t;
     }
     if (t >= ntile) return;                                    // idle consumer (ended waves do not count at s_barrier)
-    SkPre<NB> pre;
-    if (p == 0 && !(MODE == SK_ROW && gm.S > 1)) skinny_prefetch<MODE, NB>(a, lane, pre, tile);  // the waves that run the epilogue
+    // SK_QKV spreads its epilogue over the KS waves of a tile: wave p owns column groups [p * NBP, (p + 1) * NBP) - with one
+    // epilogue wave per tile the RoPE / page-table / KV-store tail of 8 column groups serialised behind the last MFMA (128 rows:
+    // 52.7 -> 35.9 us).  The other modes keep ONE epilogue wave per tile (EW = 1): spread, every wave pays the 16-stripe sum(x^2)
+    // prefetch ahead of its weight stream (gate/up 46.7 -> 52.1 us, o / down +1 us).  Per-lane epilogue inputs are prefetched
+    // before the weight stream starts.
+    constexpr int EW = MODE == SK_QKV ? KS : 1;
+    constexpr int NBP = (NB + EW - 1) / EW;
+    const bool split = MODE == SK_ROW && gm.S > 1;
+    const bool epi_wave = !split && !(MODE == SK_QKV && t == 1) && p < EW && p * NBP < NB;
+    SkPre<NBP> pre;
+    if (epi_wave) skinny_prefetch<MODE, NBP>(a, lane, pre, tile, p * NBP);
     f4 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -468,47 +477,61 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
             for (int u = 0; u < U; ++u) cw[u] = nw[u];
         }
     }
-    // ---- K phases of a tile (and, for SK_QKV, the two tiles of a PAIRED block) meet in LDS; fixed summation order
+    const int N16 = a.Npad >> 4;
+    // ---- K phases of a tile (and, for SK_QKV, the two tiles of a PAIRED block) meet in LDS; fixed summation order (phase 0, 1, ...)
     if (KS > 1 || MODE == SK_QKV) {
         SKX_BAR();                                             // every consumer is done reading x (the loaders have exited)
         float* red = (float*)smem;                             // [consumer wave][NB][64][4]  (<= 12 x 4 KiB: inside the ring)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
         SKX_BAR();
-        if (p != 0) return;
-        if (MODE == SK_QKV && t == 1) return;                  // its tile is stored by the owner of the PAIRED block (t == 0)
-        auto gather = [&](int w0, f4 (&dst)[NB]) {
+        if (MODE == SK_QKV && t == 1) return;                  // its tile is stored by the waves of the PAIRED block's first tile
+        if (p >= EW || p * NBP >= NB) return;                  // not an epilogue wave / more k phases than column groups
+        auto gather = [&](int w0, f4 (&dst)[NBP]) {            // this wave's column groups of the tile whose first wave is w0
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                f4 sum = *(const f4*)(red + ((w0 * NB + nb) * 64 + lane) * 4);
+            for (int nb = 0; nb < NBP; ++nb) {
+                const int nbg = p * NBP + nb;
+                f4 sum = f4{0.f, 0.f, 0.f, 0.f};
+                if (nbg < NB) {
+                    sum = *(const f4*)(red + ((w0 * NB + nbg) * 64 + lane) * 4);
 #pragma unroll
-                for (int pp = 1; pp < KS; ++pp) {
-                    const f4 q = *(const f4*)(red + (((w0 + pp) * NB + nb) * 64 + lane) * 4);
+                    for (int pp = 1; pp < KS; ++pp) {
+                        const f4 q = *(const f4*)(red + (((w0 + pp) * NB + nbg) * 64 + lane) * 4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sum[i] += q[i];
+                        for (int i = 0; i < 4; ++i) sum[i] += q[i];
+                    }
                 }
                 dst[nb] = sum;
             }
         };
         if (MODE == SK_QKV && t == 0) {
-            f4 pr[2][NB];
+            f4 pr[2][NBP];
             gather(0, pr[0]);
             gather(KS, pr[1]);
-            skinny_store<2, MODE, NB>(a, tile, pr, lane, pre);
+            skinny_store<2, MODE, NBP>(a, tile, pr, lane, pre, p * NBP);
             return;
         }
-        gather(w, acc);
+        f4 one[1][NBP];
+        gather(t * KS, one[0]);
+        if (split) {                                           // split-K partial, lane-linear: one 16-byte store per lane and column group
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb)
+                if (p * NBP + nb < NB) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + p * NBP + nb) * 64 + lane) * 4) = one[0][nb];
+            return;
+        }
+        skinny_store<1, MODE, NBP>(a, tile, one, lane, pre, p * NBP);
+        return;
     }
-    if (MODE == SK_ROW && gm.S > 1) {                          // split-K partial, lane-linear: one 16-byte store per lane and column group
-        const int N16 = a.Npad >> 4;
+    // KS == 1: the wave holds the whole K sum of its tile (NBP == NB)
+    if (split) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
         return;
     }
-    f4 one[1][NB];
+    f4 one[1][NBP];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) one[0][nb] = acc[nb];
-    skinny_store<1, MODE, NB>(a, tile, one, lane, pre);
+    for (int nb = 0; nb < NBP; ++nb) one[0][nb] = acc[nb];
+    skinny_store<1, MODE, NBP>(a, tile, one, lane, pre);
 }
 
 // second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue.
