@@ -60,6 +60,7 @@ struct aur_ctx {
     // workspace regions (vision)
     half_t *w_col, *w_patch, *w_xa, *w_xb, *w_xn, *w_qf, *w_kv, *w_attn, *w_h;
     float *w_metric, *w_mhat, *w_nmax, *w_sza, *w_szb;
+    int32_t* w_tome_cnt;             // [max_frames] arrival counters of the ToMe match + select launch (zero between launches)
     int32_t *w_nidx, *w_unm, *w_src, *w_dst;
     // workspace regions (llm)
     half_t *l_xn, *l_qf, *l_attn, *l_h, *l_p1, *d_x, *d_q, *d_attn, *d_h, *d_scr;
@@ -223,6 +224,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->w_mhat = k.take<float>(F * c->v_t0 * c->v_hd);
     const int64_t ta = (c->v_t0 + 1) / 2;
     c->w_nmax = k.take<float>(F * ta);
+    c->w_tome_cnt = k.take<int32_t>(F);
     c->w_nidx = k.take<int32_t>(F * ta);
     c->w_unm = k.take<int32_t>(F * ta);
     c->w_src = k.take<int32_t>(F * ta);
@@ -327,6 +329,8 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     ctx->ws_bytes = n;
     carve(ctx, ctx->ws);
     ctx->finalized = false;
+    // arrival counters of the ToMe match + select launch: zero now, and every launch leaves them at zero
+    if (ctx->w_tome_cnt) CK(hipMemset(ctx->w_tome_cnt, 0, (size_t)ctx->cfg.max_frames * 4));
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -544,7 +548,7 @@ static KvLayout vit_kv(const aur_ctx* c, int t_pad) {
 // One encoder layer on padded state x [F][t_pad][D] (in place for r == 0; x_out otherwise).  Returns via
 // *t_out the new token count; result lives in *x_res / *size_res (one of the two ping-pong buffers).
 static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, const float* size, half_t* x_alt, float* size_alt,
-                         half_t** x_res, const float** size_res, int* t_out, hipStream_t s) {
+                         half_t** x_res, const float** size_res, int* t_out, hipStream_t s, bool want_metric = false) {
     const aur_config& g = ctx->cfg;
     const VitLayerW& w = ctx->vl[l];
     const int D = g.vit_hidden, t_pad = rup(t, 32), M = F * t_pad;
@@ -567,10 +571,11 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     const float* sc = size;
     int t2 = t;
     if (rl > 0) {
-        CK(launch_tome_metric(q.kv, F, t, ctx->v_hd, ctx->w_metric, s));                   // aurora.py:639
         TomeArgs ta{};
         t2 = t - rl;
-        ta.frames = F; ta.t = t; ta.t_pad = t_pad; ta.r = rl; ta.c = ctx->v_hd; ta.d = D; ta.metric = ctx->w_metric;
+        ta.frames = F; ta.t = t; ta.t_pad = t_pad; ta.r = rl; ta.c = ctx->v_hd; ta.d = D;
+        ta.kv = &q.kv; ta.metric_out = want_metric ? ctx->w_metric : nullptr;             // metric = mean_h K, aurora.py:639
+        ta.counters = ctx->w_tome_cnt;
         ta.x = x; ta.size = size; ta.t_out_pad = rup(t2, 32); ta.x_out = x_alt; ta.size_out = size_alt;
         ta.node_max = ctx->w_nmax; ta.node_idx = ctx->w_nidx; ta.unm = ctx->w_unm; ta.src = ctx->w_src; ta.dst = ctx->w_dst;
         ta.mhat = ctx->w_mhat;
@@ -658,7 +663,7 @@ extern "C" int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const f
     half_t* xr;
     const float* sr;
     int t2;
-    int rc = vit_layer_run(ctx, layer, frames, t, r, ctx->w_xa, size ? ctx->w_sza : nullptr, ctx->w_xb, ctx->w_szb, &xr, &sr, &t2, s);
+    int rc = vit_layer_run(ctx, layer, frames, t, r, ctx->w_xa, size ? ctx->w_sza : nullptr, ctx->w_xb, ctx->w_szb, &xr, &sr, &t2, s, metric_out != nullptr);
     if (rc) return rc;
     CK(launch_unpad_rows(xr, sr, frames, t2, rup(t2, 32), D, (half_t*)x_out, size_out, s));
     const int rl = r < (t - 1) / 2 ? r : (t - 1) / 2;
@@ -699,6 +704,7 @@ extern "C" int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, c
     a.frames = frames; a.t = t; a.t_pad = t_pad; a.r = rl; a.c = c; a.d = d; a.metric = metric; a.x = ctx->w_xa;
     a.size = size ? ctx->w_sza : nullptr; a.t_out_pad = t2_pad; a.x_out = ctx->w_xb; a.size_out = ctx->w_szb;
     a.node_max = ctx->w_nmax; a.node_idx = ctx->w_nidx; a.unm = ctx->w_unm; a.src = ctx->w_src; a.dst = ctx->w_dst; a.mhat = ctx->w_mhat;
+    a.counters = ctx->w_tome_cnt;
     CK(launch_tome_step(a, s));
     CK(launch_unpad_rows(ctx->w_xb, ctx->w_szb, frames, t2, t2_pad, d, (half_t*)x_out, size_out, s));
     if (node_idx) CK(hipMemcpyAsync(node_idx, ctx->w_nidx, (size_t)frames * ta * 4, hipMemcpyDeviceToDevice, s));

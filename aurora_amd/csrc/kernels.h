@@ -90,6 +90,9 @@ struct TomeArgs {
     int32_t* src;
     int32_t* dst;
     float* mhat;                     // scratch [frames][t][c] normalised metric
+    int32_t* counters;               // [frames] zero-initialised arrival counters of the match + select launch (left at zero)
+    const KvLayout* kv;              // non-null: metric = mean over heads of these K fragments (aurora.py:639), `metric` unused
+    float* metric_out;               // with kv: optional copy of the un-normalised metric [frames][t][c]
 };
 hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s);
 // metric[f][tok][d] = mean over heads of K (read back from PAIRED K fragments of the ViT "pages")

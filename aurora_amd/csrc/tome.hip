@@ -13,9 +13,13 @@
 // changes rounding.  Cross-thread reductions compare (value, index) pairs lexicographically, which is
 // order-independent.
 //
-// Kernels per step: normalise -> match (grid over 32-row A blocks x frames, 4x4 register tiles from
-// k-major LDS images) -> select (rank / compaction, one workgroup per frame) -> merge (one wave per
-// output row, HBM-bound: reads t rows, writes t-r rows of the [frames, t, D] hidden state).
+// Three launches per step (round 1: five):
+//   1. metric + normalise: metric = mean over heads of the layer's K fragments, read once, normalised in LDS (the C-ABI entry
+//      aur_tome_step, whose metric is an input, runs the normalise half alone);
+//   2. match + select: grid over 32-row A blocks x frames, 4x4 register tiles from k-major LDS images, first-max per A row; the
+//      LAST workgroup of a frame to finish (one atomic counter per frame, release / acquire fences around it) ranks the frame's
+//      A rows and writes src / dst / unm - which workgroup that is does not matter, the inputs are complete and the rule is fixed;
+//   3. merge: one wave per output row, 16-byte loads, HBM-bound (reads t rows, writes t-r rows of the [frames, t, D] state).
 #include "kernels.h"
 
 // ------------------------------------------------------------------ metric from K fragments
@@ -65,11 +69,65 @@ __global__ void tome_normalize_kernel(const float* __restrict__ metric, int64_t 
     for (int k = 0; k < c; ++k) o[k] = m[k] / nrm;
 }
 
+// ------------------------------------------------------------------ metric from K fragments + normalise, one launch
+// A workgroup owns R = 256 / pieces token rows (pieces = 8-wide slices of a padded head): every thread sums its slice over the heads
+// (ascending, fp32: the bytes tome_metric_kernel produces) into LDS, ONE thread per row runs the k-ordered fmaf chain of the norm
+// (the contract of this file), then the row is divided and stored.  metric_out (optional) receives the un-normalised rows.
+__global__ __launch_bounds__(256) void tome_metric_norm_kernel(KvLayout kv, int frames, int t, int hd, float* __restrict__ metric_out,
+                                                               float* __restrict__ mhat) {
+    extern __shared__ __attribute__((aligned(16))) float msm[];       // [R][hdp] rows + [R] norms
+    const int pieces = kv.kblk * 4, hdp = pieces * 8;
+    const int R = 256 / pieces;
+    const int tid = threadIdx.x;
+    const int rl = tid / pieces, pc = tid - rl * pieces;
+    const int64_t row = (int64_t)blockIdx.x * R + rl;                 // over frames * t
+    const int64_t rows = (int64_t)frames * t;
+    float* nrm = msm + R * hdp;
+    const bool live = rl < R && row < rows;
+    if (live) {
+        const int f = (int)(row / t), tok = (int)(row - (int64_t)f * t);
+        const int blk = pc >> 2, g = pc & 3;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const half_t* page = kv.base + (int64_t)f * kv.page_halves;
+        for (int h = 0; h < kv.heads; ++h) {
+            const h8 v = *(const h8*)(page + kfrag_off(kv, h, tok >> 4, blk) + (g * 16 + (tok & 15)) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        const float inv = 1.0f / (float)kv.heads;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = blk * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+            msm[rl * hdp + d] = acc[j] * inv;
+        }
+    }
+    __syncthreads();
+    if (tid < R && (int64_t)blockIdx.x * R + tid < rows) {
+        const float* m = msm + tid * hdp;
+        float n2 = 0.0f;
+        for (int k = 0; k < hd; ++k) n2 = fmaf(m[k], m[k], n2);
+        nrm[tid] = sqrtf(n2);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < R * hd; idx += 256) {
+        const int r2 = idx / hd, k = idx - r2 * hd;
+        const int64_t row2 = (int64_t)blockIdx.x * R + r2;
+        if (row2 >= rows) break;
+        const float v = msm[r2 * hdp + k];
+        if (metric_out) metric_out[row2 * hd + k] = v;
+        mhat[row2 * hd + k] = v / nrm[r2];
+    }
+}
+
 // ------------------------------------------------------------------ match (tome.py:52-60)
 #define TM_RA 32      // A rows per workgroup
 #define TM_JB 128     // B rows per pass
-__global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict__ mhat, int t, int c,
-                                                         float* __restrict__ node_max, int32_t* __restrict__ node_idx) {
+__global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict__ mhat, int t, int c, int r,
+                                                         float* __restrict__ node_max, int32_t* __restrict__ node_idx,
+                                                         int32_t* __restrict__ counters, int32_t* __restrict__ unm,
+                                                         int32_t* __restrict__ src, int32_t* __restrict__ dst) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* As = tsm;                         // [c][TM_RA]
     float* Bs = tsm + c * TM_RA;             // [c][TM_JB]
@@ -155,21 +213,25 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict
             node_idx[(int64_t)f * ta + i] = bi;
         }
     }
-}
-
-// ------------------------------------------------------------------ select (tome.py:61-69)
-__global__ __launch_bounds__(512) void tome_select_kernel(const float* __restrict__ node_max,
-                                                          const int32_t* __restrict__ node_idx, int t, int r,
-                                                          int32_t* __restrict__ unm, int32_t* __restrict__ src,
-                                                          int32_t* __restrict__ dst) {
-    extern __shared__ __attribute__((aligned(16))) float ssm[];
-    const int ta = (t + 1) >> 1;
-    float* nm = ssm;                   // [ta]
-    int* is_src = (int*)(ssm + ta);    // [ta]
-    const int f = blockIdx.x;
-    for (int i = threadIdx.x; i < ta; i += blockDim.x) nm[i] = node_max[(int64_t)f * ta + i];
+    // ---- select (tome.py:61-69) by the last workgroup of the frame: rank by (node_max desc, i asc); src = the r best in rank
+    //      order, unm = the rest in ascending i.  Every workgroup's rows are released (agent scope: they sit in other XCDs' L2s)
+    //      before its arrival is counted, and acquired by the one that finds the frame complete.
+    __shared__ int s_last;
+    __threadfence();
     __syncthreads();
-    for (int i = threadIdx.x; i < ta; i += blockDim.x) {
+    if (tid == 0) {
+        const int arrived = atomicAdd(counters + f, 1);
+        s_last = arrived == (int)gridDim.x - 1;
+        if (s_last) counters[f] = 0;                               // ready for the next layer
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float* nm = tsm;                   // [ta]   (the match images are dead)
+    int* is_src = (int*)(tsm + ta);    // [ta]
+    for (int i = tid; i < ta; i += 256) nm[i] = __builtin_nontemporal_load(node_max + (int64_t)f * ta + i);
+    __syncthreads();
+    for (int i = tid; i < ta; i += 256) {
         const float v = nm[i];
         int rank = 0;
         for (int i2 = 0; i2 < ta; ++i2) {
@@ -179,11 +241,11 @@ __global__ __launch_bounds__(512) void tome_select_kernel(const float* __restric
         is_src[i] = rank < r ? 1 : 0;
         if (rank < r) {
             src[(int64_t)f * r + rank] = i;
-            dst[(int64_t)f * r + rank] = node_idx[(int64_t)f * ta + i];
+            dst[(int64_t)f * r + rank] = __builtin_nontemporal_load(node_idx + (int64_t)f * ta + i);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ta; i += blockDim.x) {
+    for (int i = tid; i < ta; i += 256) {
         if (!is_src[i]) {
             int before = 0;
             for (int i2 = 0; i2 < i; ++i2) before += is_src[i2];
@@ -193,28 +255,34 @@ __global__ __launch_bounds__(512) void tome_select_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ merge (tome.py:71-81, 207-219)
-#define TMG_MAXC 8    // h4 chunks per lane -> d <= 2048
+// One wave per output row; a lane owns chunks lane, lane + 64, ... of V halves (V = 8: 16-byte loads / stores when d % 8 == 0).
+// Sum order per element: the B (or unmerged A) row first, then the merged A rows in rank order - as the oracle does.
+template <int V, int MAXC>
 __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
+    typedef half_t hv __attribute__((ext_vector_type(V)));
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y;
     if (o >= a.t_out_pad) return;
     const int ta = (a.t + 1) >> 1, nu = ta - a.r, t_out = a.t - a.r;
-    const int nchunk = a.d >> 2;
+    const int nchunk = a.d / V;
     half_t* orow = a.x_out + ((int64_t)f * a.t_out_pad + o) * a.d;
     float* so = a.size_out + (int64_t)f * a.t_out_pad + o;
     if (o >= t_out) {       // padding rows: zeros, size 1
+        hv z;
 #pragma unroll
-        for (int i = 0; i < TMG_MAXC; ++i) {
+        for (int j = 0; j < V; ++j) z[j] = (half_t)0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + i * 64;
-            if (c < nchunk) *(h4*)(orow + c * 4) = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            if (c < nchunk) *(hv*)(orow + c * V) = z;
         }
         if (lane == 0) *so = 1.0f;
         return;
     }
     const half_t* xf = a.x + (int64_t)f * a.t_pad * a.d;
     const float* sf = a.size ? a.size + (int64_t)f * a.t_pad : nullptr;
-    float acc[TMG_MAXC][4];
+    float acc[MAXC][V];
     float st;
     int tok;
     if (o < nu) tok = 2 * a.unm[(int64_t)f * nu + o];
@@ -223,12 +291,12 @@ __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
         const float s0 = sf ? sf[tok] : 1.0f;
         st = s0;
 #pragma unroll
-        for (int i = 0; i < TMG_MAXC; ++i) {
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + i * 64;
             if (c < nchunk) {
-                const h4 v = *(const h4*)(xf + (int64_t)tok * a.d + c * 4);
+                const hv v = *(const hv*)(xf + (int64_t)tok * a.d + c * V);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (float)v[j] * s0;
+                for (int j = 0; j < V; ++j) acc[i][j] = (float)v[j] * s0;
             }
         }
     }
@@ -238,15 +306,15 @@ __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
         const int32_t* srcf = a.src + (int64_t)f * a.r;
         for (int q = 0; q < a.r; ++q) {
             if (dstf[q] != jrow) continue;
-            const int ts = 2 * srcf[q];
-            const float ss = sf ? sf[ts] : 1.0f;
+            const int tsq = 2 * srcf[q];
+            const float ss = sf ? sf[tsq] : 1.0f;
 #pragma unroll
-            for (int i = 0; i < TMG_MAXC; ++i) {
+            for (int i = 0; i < MAXC; ++i) {
                 const int c = lane + i * 64;
                 if (c < nchunk) {
-                    const h4 v = *(const h4*)(xf + (int64_t)ts * a.d + c * 4);
+                    const hv v = *(const hv*)(xf + (int64_t)tsq * a.d + c * V);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < V; ++j) {
                         const float p = (float)v[j] * ss;
                         acc[i][j] = acc[i][j] + p;
                     }
@@ -256,32 +324,40 @@ __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < TMG_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + i * 64;
         if (c < nchunk) {
-            h4 ov;
+            hv ov;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ov[j] = (half_t)(acc[i][j] / st);
-            *(h4*)(orow + c * 4) = ov;
+            for (int j = 0; j < V; ++j) ov[j] = (half_t)(acc[i][j] / st);
+            *(hv*)(orow + c * V) = ov;
         }
     }
     if (lane == 0) *so = st;
 }
 
 hipError_t tome_init() {
-    return hipFuncSetAttribute((const void*)tome_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute((const void*)tome_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // + 4 bytes of static LDS (the select flag)
 }
 
 hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s) {
     const int ta = (a.t + 1) >> 1;
-    if (a.r <= 0 || a.r > (a.t - 1) / 2 || a.d > TMG_MAXC * 256 || (a.d & 3) || ta > 4096) return hipErrorInvalidValue;
+    if (a.r <= 0 || a.r > (a.t - 1) / 2 || a.d > 2048 || (a.d & 3) || ta > 4096 || !a.counters) return hipErrorInvalidValue;
     const int64_t rows = (int64_t)a.frames * a.t;
-    hipLaunchKernelGGL(tome_normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a.metric, rows, a.c, a.mhat);
-    const size_t lds_m = (size_t)(a.c * (TM_RA + TM_JB) + TM_RA * 64) * sizeof(float);
-    hipLaunchKernelGGL(tome_match_kernel, dim3((ta + TM_RA - 1) / TM_RA, a.frames), dim3(256), lds_m, s, a.mhat, a.t, a.c,
-                       a.node_max, a.node_idx);
-    hipLaunchKernelGGL(tome_select_kernel, dim3(a.frames), dim3(512), (size_t)ta * 8, s, a.node_max, a.node_idx, a.t, a.r,
-                       a.unm, a.src, a.dst);
-    hipLaunchKernelGGL(tome_merge_kernel, dim3((a.t_out_pad + 3) / 4, a.frames), dim3(256), 0, s, a);
+    if (a.kv) {                                                // metric from this layer's K fragments, normalised in the same launch
+        const int pieces = a.kv->kblk * 4, R = 256 / pieces;
+        if (pieces < 1 || pieces > 256 || a.c > pieces * 8) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(tome_metric_norm_kernel, dim3((unsigned)((rows + R - 1) / R)), dim3(256), (size_t)(R * pieces * 8 + R) * 4, s,
+                           *a.kv, a.frames, a.t, a.c, a.metric_out, a.mhat);
+    } else {
+        hipLaunchKernelGGL(tome_normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a.metric, rows, a.c, a.mhat);
+    }
+    size_t lds_m = (size_t)(a.c * (TM_RA + TM_JB) + TM_RA * 64) * sizeof(float);
+    if (lds_m < (size_t)ta * 8) lds_m = (size_t)ta * 8;        // the select tail re-uses the images: [ta] values + [ta] flags
+    hipLaunchKernelGGL(tome_match_kernel, dim3((ta + TM_RA - 1) / TM_RA, a.frames), dim3(256), lds_m, s, a.mhat, a.t, a.c, a.r,
+                       a.node_max, a.node_idx, a.counters, a.unm, a.src, a.dst);
+    const dim3 grid((a.t_out_pad + 3) / 4, a.frames);
+    if ((a.d & 7) == 0) hipLaunchKernelGGL((tome_merge_kernel<8, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tome_merge_kernel<4, 8>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--nseq", type=int, default=1, help="sequences per prefill pass for the pre_* kernels (<= batch)")
+    ap.add_argument("--mask-cus", type=int, default=0, help="time the kernels on a stream restricted to this many CUs of every XCD")
     args = ap.parse_args()
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup
@@ -41,6 +42,10 @@ def main():
         emb = (torch.randn(_rup(L0, 32), d, generator=g, device="cuda") * 0.02).half()
         eng.prefill(b, emb, L0)
     torch.cuda.synchronize()
+    if args.mask_cus > 0:
+        from aurora_amd.streams import cu_masked_stream
+        torch.cuda.set_stream(cu_masked_stream(args.mask_cus, from_top=True))
+        eng.set_option("gemm_max_wgs", 8 * args.mask_cus)
     eng.set_option("microbench_prefill_nseq", min(args.nseq, B))
     M = _rup(L0, 32) * min(args.nseq, B)
     kv_bytes = B * (L0 + 1) * 2 * d * 2
