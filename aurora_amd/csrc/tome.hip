@@ -209,27 +209,28 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict
                 bv = -INFINITY;
                 bi = 0;
             }
-            node_max[(int64_t)f * ta + i] = bv;
-            node_idx[(int64_t)f * ta + i] = bi;
+            // agent-scope stores / loads for the hand-over below: the frame's workgroups sit on different XCDs, whose L2s are not
+            // coherent for plain accesses.  (Full release / acquire fences - an L2 write-back per workgroup - cost ~100 us per launch.)
+            __hip_atomic_store(node_max + (int64_t)f * ta + i, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(node_idx + (int64_t)f * ta + i, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- select (tome.py:61-69) by the last workgroup of the frame: rank by (node_max desc, i asc); src = the r best in rank
-    //      order, unm = the rest in ascending i.  Every workgroup's rows are released (agent scope: they sit in other XCDs' L2s)
-    //      before its arrival is counted, and acquired by the one that finds the frame complete.
+    //      order, unm = the rest in ascending i.  A workgroup's rows have reached the coherence point (vmcnt 0) before its arrival
+    //      is counted; the workgroup that finds the frame complete reads them back at agent scope.
     __shared__ int s_last;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const int arrived = atomicAdd(counters + f, 1);
+        const int arrived = __hip_atomic_fetch_add(counters + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = arrived == (int)gridDim.x - 1;
-        if (s_last) counters[f] = 0;                               // ready for the next layer
+        if (s_last) __hip_atomic_store(counters + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next layer
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     float* nm = tsm;                   // [ta]   (the match images are dead)
     int* is_src = (int*)(tsm + ta);    // [ta]
-    for (int i = tid; i < ta; i += 256) nm[i] = __builtin_nontemporal_load(node_max + (int64_t)f * ta + i);
+    for (int i = tid; i < ta; i += 256) nm[i] = __hip_atomic_load(node_max + (int64_t)f * ta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     for (int i = tid; i < ta; i += 256) {
         const float v = nm[i];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict
         is_src[i] = rank < r ? 1 : 0;
         if (rank < r) {
             src[(int64_t)f * r + rank] = i;
-            dst[(int64_t)f * r + rank] = __builtin_nontemporal_load(node_idx + (int64_t)f * ta + i);
+            dst[(int64_t)f * r + rank] = __hip_atomic_load(node_idx + (int64_t)f * ta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();

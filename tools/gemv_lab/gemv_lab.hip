@@ -330,6 +330,152 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skx_kernel(Args a) {
     for (int nb = 0; nb < NB; ++nb) *(f4*)(a.out + ((((int64_t)s * a.N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
 }
 
+// ------------------------------------------------------------------------------------------------ B2: x through LDS, flags instead of barriers
+// Same data flow as skx_kernel, but no s_barrier in the K loop: the loader waves publish a chunk by bumping ready[buf] in LDS once
+// their DMAs have landed, consumers poll that word before the chunk's first read and bump done[buf] after its last one; a loader
+// re-fills buffer b for chunk ci only when done[b] shows that every consumer has left chunk ci - NBUF.  Waves drift apart by up to
+// NBUF - 1 chunks instead of meeting 16-32 times per kernel.
+__device__ __forceinline__ unsigned lds_load_u32(const unsigned* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_add_u32(unsigned* p, unsigned x) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)p), "v"(x) : "memory");
+}
+
+template <int T_MAX, int KS, int KC, int NBUF, int U, int NL, int NB>
+__global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skf_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB, then the flag words
+    constexpr int NCW = T_MAX * KS, Q = KC / KS;
+    constexpr int PIECES = KC * NB / NL;
+    constexpr int CHUNK = KC * NB * 1024;
+    static_assert((KC * NB) % NL == 0 && KC % KS == 0 && (Q % U == 0 || U % Q == 0), "geometry");
+    static_assert((NBUF - 1) * PIECES <= 63, "vmcnt is a 6-bit counter");
+    unsigned* ready = (unsigned*)(smem + NBUF * CHUNK);                 // [NBUF] loader waves that have landed their pieces, cumulative
+    unsigned* done = ready + NBUF;                                      // [NBUF] consumer waves that have left the buffer, cumulative
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int ntile = a.tiles_lo + (c < a.n_hi ? 1 : 0);
+    const int tile0 = c * a.tiles_lo + (c < a.n_hi ? c : a.n_hi);
+    const int K32 = a.K32, KE = K32 / a.S, kb = s * KE;
+    const int nchunk = (KE + KC - 1) / KC;
+    const unsigned nca = (unsigned)(ntile * KS);                        // active consumer waves
+    if (tid < 2 * NBUF) ready[tid] = 0u;
+    __syncthreads();
+
+    if (w >= NCW) {                                            // ---------------- loader waves
+        const int lw = w - NCW;
+        auto issue = [&](int ci) {
+            const int b = ci % NBUF;
+            if (ci >= NBUF) {                                  // the buffer's previous chunk must have been left by every consumer
+                const unsigned want = nca * (unsigned)(ci / NBUF);
+                while (lds_load_u32(done + b) < want) __builtin_amdgcn_s_sleep(1);
+            }
+            char* buf = smem + b * CHUNK;
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                const int piece = q * NL + lw, kk = piece / NB, nb = piece % NB;
+                int kr = ci * KC + kk;
+                kr = kr < KE ? kr : KE - 1;
+                glds16(a.xf + ((int64_t)nb * K32 + kb + kr) * FRAG + lane * 8, buf + piece * 1024);
+            }
+        };
+        int next = 0;
+        for (; next < NBUF - 1 && next < nchunk; ++next) issue(next);
+        for (int ci = 0; ci < nchunk; ++ci) {
+            switch (next - ci - 1) {
+                case 0: wait_vm<0>(); break;
+                case 1: wait_vm<PIECES>(); break;
+                case 2: wait_vm<(NBUF > 3 ? 2 : 0) * PIECES>(); break;
+                case 3: wait_vm<(NBUF > 4 ? 3 : 0) * PIECES>(); break;
+                case 4: wait_vm<(NBUF > 5 ? 4 : 0) * PIECES>(); break;
+                case 5: wait_vm<(NBUF > 6 ? 5 : 0) * PIECES>(); break;
+                case 6: wait_vm<(NBUF > 7 ? 6 : 0) * PIECES>(); break;
+                default: wait_vm<0>(); break;
+            }
+            if (lane == 0) lds_add_u32(ready + ci % NBUF, 1u);
+            if (next < nchunk) {
+                issue(next);
+                ++next;
+            }
+        }
+        return;
+    }
+    const int t = w / KS, p = w % KS;
+    if (t >= ntile) return;
+    const int tile = tile0 + t;
+    f4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    const half_t* wbase = a.W + ((int64_t)tile * K32 + kb) * FRAG + lane * 8;
+    const int NS = nchunk * Q;
+    auto kof = [&](int j, bool& valid) {
+        const int kr = (j / Q) * KC + (j % Q) * KS + p;
+        valid = j < NS && kr < KE;
+        return valid ? kr : KE - 1;
+    };
+    h8 cw[U], nw[U];
+    bool vv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) cw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(u, vv) * FRAG));
+    for (int j0 = 0; j0 < NS; j0 += U) {
+        const bool more = j0 + U < NS;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(j0 + U + u, vv) * FRAG));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            const int ci = j / Q, kk = (j % Q) * KS + p;
+            if (j < NS && j % Q == 0) {                        // first step of chunk ci: leave the previous buffer, wait for this one
+                if (ci > 0 && lane == 0) lds_add_u32(done + (ci - 1) % NBUF, 1u);
+                const unsigned want = (unsigned)NL * (unsigned)(ci / NBUF + 1);
+                while (lds_load_u32(ready + ci % NBUF) < want) __builtin_amdgcn_s_sleep(0);
+            }
+            const char* buf = smem + (ci % NBUF) * CHUNK + lane * 16;
+            bool valid;
+            (void)kof(j, valid);
+            h8 xr[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) xr[nb] = *(const h8*)(buf + (kk * NB + nb) * 1024);
+            if (!valid) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) xr[nb] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(cw[u], xr[nb], acc[nb]);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) cw[u] = nw[u];
+        }
+    }
+    if (KS > 1) {                                              // fixed-order reduction over the k phases (the loaders have exited)
+        BAR();
+        float* red = (float*)smem;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
+        BAR();
+        if (p != 0) return;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f4 sum = acc[nb];
+#pragma unroll
+            for (int pp = 1; pp < KS; ++pp) {
+                const f4 q = *(const f4*)(red + (((w + pp) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum[i] += q[i];
+            }
+            acc[nb] = sum;
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) *(f4*)(a.out + ((((int64_t)s * a.N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
+}
+
 // split-K second stage: out[0] = sum_s part[s] in fixed order (stands in for the residual / norm epilogue of the product)
 __global__ __launch_bounds__(256) void reduce_kernel(const float* part, float* out, int64_t n4, int S) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -384,6 +530,18 @@ static void launch_skx(dim3 grid, const Args& a, hipStream_t st) {
         once = true;
     }
     hipLaunchKernelGGL((skx_kernel<T_MAX, KS, KC, NBUF, U, ROT, NL, NB, LM>), grid, dim3(64 * (T_MAX * KS + NL)), lds, st, a);
+}
+
+template <int T_MAX, int KS, int KC, int NBUF, int U, int NL, int NB>
+static void launch_skf(dim3 grid, const Args& a, hipStream_t st) {
+    constexpr int ring = NBUF * KC * NB * 1024, red = T_MAX * KS * NB * 1024;
+    constexpr int lds = (ring > red ? ring : red) + 64;
+    static bool once = false;
+    if (!once) {
+        CKH(hipFuncSetAttribute((const void*)skf_kernel<T_MAX, KS, KC, NBUF, U, NL, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once = true;
+    }
+    hipLaunchKernelGGL((skf_kernel<T_MAX, KS, KC, NBUF, U, NL, NB>), grid, dim3(64 * (T_MAX * KS + NL)), lds, st, a);
 }
 
 template <int NB>
@@ -485,6 +643,10 @@ static void lab(int iters, const char* only) {
             if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL8", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 8, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
         } else if (nm == "qkv") {
             run("skx T3 KS4 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<3, 4, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skf T3 KS4 flags KCx NBUF4 U4 NL4", [&](int cp) { launch_skf<3, 4, KC, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skf T3 KS4 flags KC4 NBUF4 U4 NL4", [&](int cp) { launch_skf<3, 4, 4, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skf T3 KS4 flags KC4 NBUF(8|4) U4 NL4", [&](int cp) { launch_skf<3, 4, 4, (NB <= 4 ? 8 : 4), 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skf T3 KS4 flags KC4 NBUF4 U8 NL4", [&](int cp) { launch_skf<3, 4, 4, 4, 8, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
             run("skx T6 KS2 S2 dma NL4 + reduce", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 6, 0), st); red(2); }, true, 0);
             run("skx T12 KS1 S4 dma NL4 + reduce", [&](int cp) { launch_skx<12, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(64, 4), mk(cp, part, 4, 12, 0), st); red(4); }, true, 0);
             run("skx T12 KS1 S4 dma NL4 main only", [&](int cp) { launch_skx<12, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(64, 4), mk(cp, part, 4, 12, 0), st); }, false, 0);
@@ -496,6 +658,9 @@ static void lab(int iters, const char* only) {
             run("skx T3 KS4 reg R2 U4 NL4 KC8", [&](int cp) { launch_skx<3, 4, 8, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
         } else if (nm == "gateup") {
             run("skx T6 KS2 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skf T6 KS2 flags KCx NBUF4 U4 NL4", [&](int cp) { launch_skf<6, 2, KC, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skf T6 KS2 flags KC4 NBUF4 U4 NL4", [&](int cp) { launch_skf<6, 2, 4, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skf T6 KS2 flags KC2 NBUF8 U4 NL4", [&](int cp) { launch_skf<6, 2, 2, 8, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
             run("skx T11 KS1 S2 dma NL4 + reduce", [&](int cp) { launch_skx<11, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 10, 96), st); red(2); }, true, 0);
             run("skx T11 KS1 S2 dma NL4 main only", [&](int cp) { launch_skx<11, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 2), mk(cp, part, 2, 10, 96), st); }, false, 0);
             run("skx T6 KS2 reg R2 U4 NL4", [&](int cp) { launch_skx<6, 2, KC, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
@@ -504,6 +669,7 @@ static void lab(int iters, const char* only) {
             run("skx T6 KS2 reg R2 U4 NL4 KC8", [&](int cp) { launch_skx<6, 2, 8, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
         } else {
             run("skx T8 KS1 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<8, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
+            run("skf T8 KS1 flags KCx NBUF4 U4 NL4", [&](int cp) { launch_skf<8, 1, KC, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
             run("skx T8 KS1 reg R2 U4 NL4", [&](int cp) { launch_skx<8, 1, KC, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 7, 208), st); }, true, 0);
         }
         CKH(hipFree(W)); CKH(hipFree(xf)); CKH(hipFree(out)); CKH(hipFree(ref)); CKH(hipFree(part));
