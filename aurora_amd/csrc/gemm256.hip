@@ -21,6 +21,7 @@
 //    of a prefill tile (K = 4096).  With the overlap only the store drain (vmcnt(0) before the next tile's first barrier) is
 //    left exposed.  LDS is free for the next prologue as soon as the K loop's last, group-aligning barrier has been passed.
 #include "gemm_epilogue.h"
+#include "tile_order.h"
 
 #define G2_LDS (160 * 1024)
 #define G2_SLOT 16384
@@ -273,11 +274,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     const int nbn = a.Npad >> 8;
     const int nbm = (a.M + 255) >> 8;
     const int nwg = nbn * nbm;
-    // tile of a block id: XCD-aware bijective remap (guide T1), then super-rows of 4 M-tiles, column-major inside: an XCD's 32
-    // consecutive tiles are 4 (M) x 8 (N), so every weight half-tile is fetched from HBM once and re-used from the XCD's L2 by 4
-    // workgroups, every activation tile by 8.  gridDim.x is a multiple of 8 whenever a workgroup walks more than one tile, so
-    // its tiles keep the XCD (bid % 8) the remap assumes.
+    // tile of a block id.  tile_order 1 (default): rounds of gridDim.x tiles are compact blocks of the tile space, one 4 x sn
+    // sub-block per XCD (tile_order.h).  tile_order 0 (round 1 / early round 2): XCD-aware bijective remap (guide T1), then super-rows
+    // of 4 M-tiles, column-major inside - every XCD walks its own contiguous range of the tile space, so an XCD's 32 consecutive tiles
+    // are 4 (M) x 8 (N) and nothing is shared between XCDs in time.  gridDim.x is a multiple of 8 whenever a workgroup walks more than
+    // one tile, so its tiles keep the XCD (bid % 8) both orders assume.
+    TileOrder ord;
+    tile_order_init(ord, nbm, nbn, a.tile_order == 1 ? (int)gridDim.x : 0);
     auto tile_of = [&](int bid, int& bm, int& bn) {
+        if (ord.full > 0 || a.tile_order == 1) {
+            tile_of_bid(ord, bid, bm, bn);
+            return;
+        }
         const int xcd = bid & 7, q = nwg >> 3, rem8 = nwg & 7;
         const int lid = (xcd < rem8 ? xcd * (q + 1) : rem8 * (q + 1) + (xcd - rem8) * q) + (bid >> 3);
         const int sr = lid / (4 * nbn), rem = lid - sr * 4 * nbn;

@@ -32,6 +32,7 @@ struct GemmArgs {
     int gemm_mode;          // 0: 128x128 kernel only, 1: auto, 2: force 256x256 when Npad % 256 == 0
     int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
     int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
+    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
                             // grid is the same for every shape) separate the shapes - profiles/*_kernel_stats.txt, *_pmc.json

@@ -59,6 +59,9 @@ def parse():
     p.add_argument("--overlap-steps", type=int, default=-1,
                    help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
                         "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
+    p.add_argument("--sync-chunks", action="store_true",
+                   help="--overlap 1: synchronise the decode stream after every chunk (profiling aid: rocprofv3 --kernel-trace needs the "
+                        "queue of pending hipGraph launches kept short; costs a host round trip per chunk)")
     p.add_argument("--front-cus", type=int, default=0,
                    help="--overlap 1 / --pipeline: run the front-end stream on this many CUs of every XCD (hipExtStreamCreateWithCUMask; "
                         "--overlap 1 defaults to 16)")
@@ -67,6 +70,7 @@ def parse():
     p.add_argument("--gemm-cus", type=int, default=0,
                    help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
                         "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
+    p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,6 +257,8 @@ def main():
         eng.set_option("gemm_mode", args.gemm_mode)
     if args.gemm_cus > 0:
         eng.set_option("gemm_max_wgs", args.gemm_cus)
+    if args.gemm_tile_order >= 0:
+        eng.set_option("gemm_tile_order", args.gemm_tile_order)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B
@@ -291,9 +297,10 @@ def main():
         """Decode of the batch in `bank`, result copy (synchronises the decode stream) and the cross-rank gather.
         gather=False for rank-local passes (the instrumented step runs on rank 0 only: no collective may be in it)."""
         eng.select_bank(bank)
-        if args.decode_chunk > 0:                                  # profiling aid: bound the number of queued graph launches
-            for s0 in range(0, N - 1, args.decode_chunk):
-                eng.decode(min(args.decode_chunk, N - 1 - s0))
+        if args.decode_chunk > 0 or args.sync_chunks:              # profiling aid: bound the number of queued graph launches
+            dc = args.decode_chunk if args.decode_chunk > 0 else 64
+            for s0 in range(0, N - 1, dc):
+                eng.decode(min(dc, N - 1 - s0))
                 torch.cuda.current_stream().synchronize()
         else:
             eng.decode(N - 1)
@@ -361,6 +368,8 @@ def main():
             for g in range(NG):
                 refill(g, collect=not fill, timed=timed)
                 eng.decode((offs[g + 1] if g + 1 < NG else S) - offs[g])
+                if args.sync_chunks:
+                    torch.cuda.current_stream().synchronize()
             if fill:
                 return None
             got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()         # synchronises: the cycle has run
@@ -441,6 +450,8 @@ def main():
                         sD.wait_event(evm)
                     if n - k1 > 0:
                         eng.decode(n - k1)
+                    if args.sync_chunks:
+                        sD.synchronize()
                 got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
                 o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
                 if world > 1:
