@@ -67,14 +67,14 @@ struct SkPre {
     int pos[NB];
     half_t* page[NB];
 };
-template <int MODE, int NB>
+template <int MODE, int NB, bool WITH_RSTD = true>
 __device__ __forceinline__ void skinny_prefetch(const SkinnyArgs& a, const int lane, SkPre<NB>& pre, const int tile0 = 0, const int nb_base = 0) {
     const int c = lane & 15;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int b = (nb_base + nb) * 16 + c;
         const bool live = b >= a.b_lo && b < a.b_hi;
-        pre.rstd[nb] = (a.ssq_in && live) ? ssq_to_rstd(a.ssq_in, b, a.K, a.norm_eps) : 1.f;
+        pre.rstd[nb] = (WITH_RSTD && a.ssq_in && live) ? ssq_to_rstd(a.ssq_in, b, a.K, a.norm_eps) : 1.f;
         pre.pos[nb] = 0;
         pre.page[nb] = nullptr;
         if (MODE == SK_QKV && live) {
@@ -363,7 +363,7 @@ struct SkxGeom {
 
 template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
 __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(SkinnyArgs a, SkxGeom gm) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB ring, then 1/rms of every batch row
     constexpr int NCW = T_MAX * KS, Q = KC / KS;                        // consumer waves; steps per wave per chunk
     constexpr int PIECES = KC * NB / NL;                                // DMA instructions per chunk per loader wave
     constexpr int CHUNK_BYTES = KC * NB * 1024;
@@ -371,7 +371,8 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     static_assert((KC * NB) % NL == 0, "pieces per chunk must split evenly over the loader waves");
     static_assert((NBUF - 1) * PIECES <= 63, "vmcnt is a 6-bit counter");
     static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
-    static_assert(MODE != SK_QKV || T_MAX == 3, "SK_QKV: a workgroup owns one PAIRED block + one V tile");
+    static_assert(MODE != SK_QKV || T_MAX % 3 == 0, "SK_QKV: a workgroup owns T_MAX / 3 units of one PAIRED block + one V tile");
+    float* rstd_lds = (float*)(smem + NBUF * CHUNK_BYTES);              // [AUR_MAX_BATCH], written by loader wave 0 before the first barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = blockIdx.x, s = blockIdx.y;
@@ -393,6 +394,14 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         };
         int next = 0;
         for (; next < NBUF - 1 && next < nchunk; ++next) issue(next);
+        // folded RMSNorm: 1/rms of every live batch row ONCE per workgroup (16 accumulator stripes per row), while the first chunks
+        // fly; the first chunk barrier publishes it to the epilogue waves.  (Per epilogue wave it was 16 x NB loads ahead of the
+        // weight stream - what made a spread epilogue lose on the gate/up kernel.)
+        if (lw == 0) {
+            for (int b = lane; b < AUR_MAX_BATCH; b += 64)
+                rstd_lds[b] = (a.ssq_in && b >= a.b_lo && b < a.b_hi) ? ssq_to_rstd(a.ssq_in, b, a.K, a.norm_eps) : 1.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         for (int ci = 0; ci < nchunk; ++ci) {
             switch (next - ci - 1) {                           // chunks that may stay in flight once chunk ci has landed (<= NBUF - 2)
                 case 0: wait_vmcnt<0>(); break;
@@ -413,26 +422,27 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         return;
     }
     const int t = w / KS, p = w % KS;
+    constexpr int UN = MODE == SK_QKV ? T_MAX / 3 : 1;         // SK_QKV units per workgroup: unit u = c + u * gridDim.x
     int ntile, tile;
     if (MODE == SK_QKV) {
-        ntile = 3;
-        tile = t < 2 ? 2 * c + t : gm.v_tile0 + c;
+        ntile = T_MAX;
+        tile = t < 2 * UN ? 2 * (c + (t >> 1) * (int)gridDim.x) + (t & 1) : gm.v_tile0 + c + (t - 2 * UN) * (int)gridDim.x;
     } else {
         ntile = gm.tiles_lo + (c < gm.n_hi ? 1 : 0);
         tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + t;
     }
     if (t >= ntile) return;                                    // idle consumer (ended waves do not count at s_barrier)
-    // SK_QKV spreads its epilogue over the KS waves of a tile: wave p owns column groups [p * NBP, (p + 1) * NBP) - with one
-    // epilogue wave per tile the RoPE / page-table / KV-store tail of 8 column groups serialised behind the last MFMA (128 rows:
-    // 52.7 -> 35.9 us).  The other modes keep ONE epilogue wave per tile (EW = 1): spread, every wave pays the 16-stripe sum(x^2)
-    // prefetch ahead of its weight stream (gate/up 46.7 -> 52.1 us, o / down +1 us).  Per-lane epilogue inputs are prefetched
-    // before the weight stream starts.
-    constexpr int EW = MODE == SK_QKV ? KS : 1;
-    constexpr int NBP = (NB + EW - 1) / EW;
+    // Epilogue waves.  SK_QKV spreads the RoPE / page-table / KV-store tail: the 2 * KS waves of a PAIRED block share its column
+    // groups (NBPP each), the KS waves of a V tile theirs (NBPV each) - with one epilogue wave per tile 8 column groups serialised
+    // behind the last MFMA (128 rows: 52.7 -> 36 us).  The other modes keep ONE epilogue wave per tile (k phase 0).
+    constexpr int NBPP = MODE == SK_QKV ? (NB + 2 * KS - 1) / (2 * KS) : NB;      // PAIRED block: groups per wave
+    constexpr int NBPV = MODE == SK_QKV ? (NB + KS - 1) / KS : NB;                // V tile / every other mode
     const bool split = MODE == SK_ROW && gm.S > 1;
-    const bool epi_wave = !split && !(MODE == SK_QKV && t == 1) && p < EW && p * NBP < NB;
-    SkPre<NBP> pre;
-    if (epi_wave) skinny_prefetch<MODE, NBP>(a, lane, pre, tile, p * NBP);
+    const bool pair_tile = MODE == SK_QKV && t < 2 * UN;
+    const int eg0 = MODE != SK_QKV ? 0 : pair_tile ? ((t & 1) * KS + p) * NBPP : p * NBPV;       // first column group of this wave's epilogue
+    const bool epi_wave = !split && (MODE == SK_QKV ? eg0 < NB : p == 0);
+    SkPre<NBPV> pre;
+    if (epi_wave) skinny_prefetch<MODE, NBPV, false>(a, lane, pre, tile, eg0);   // positions / page pointers (1/rms comes from LDS)
     f4 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -478,6 +488,14 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         }
     }
     const int N16 = a.Npad >> 4;
+    auto load_rstd = [&](auto& pr, int g0) {                   // 1/rms of this lane's batch rows (published by loader wave 0)
+        constexpr int cnt = sizeof(pr.rstd) / sizeof(float);
+#pragma unroll
+        for (int nb = 0; nb < cnt; ++nb) {
+            const int b = (g0 + nb) * 16 + (lane & 15);
+            pr.rstd[nb] = b < AUR_MAX_BATCH ? rstd_lds[b] : 1.f;
+        }
+    };
     // ---- K phases of a tile (and, for SK_QKV, the two tiles of a PAIRED block) meet in LDS; fixed summation order (phase 0, 1, ...)
     if (KS > 1 || MODE == SK_QKV) {
         SKX_BAR();                                             // every consumer is done reading x (the loaders have exited)
@@ -485,12 +503,14 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
         SKX_BAR();
-        if (MODE == SK_QKV && t == 1) return;                  // its tile is stored by the waves of the PAIRED block's first tile
-        if (p >= EW || p * NBP >= NB) return;                  // not an epilogue wave / more k phases than column groups
-        auto gather = [&](int w0, f4 (&dst)[NBP]) {            // this wave's column groups of the tile whose first wave is w0
+        if (!epi_wave && !split) return;
+        if (split && p != 0) return;
+        // column groups [g0, g0 + cnt) of the tile whose first wave is w0
+        auto gather = [&](int w0, int g0, auto& dst) {
+            constexpr int cnt = sizeof(dst) / sizeof(f4);
 #pragma unroll
-            for (int nb = 0; nb < NBP; ++nb) {
-                const int nbg = p * NBP + nb;
+            for (int nb = 0; nb < cnt; ++nb) {
+                const int nbg = g0 + nb;
                 f4 sum = f4{0.f, 0.f, 0.f, 0.f};
                 if (nbg < NB) {
                     sum = *(const f4*)(red + ((w0 * NB + nbg) * 64 + lane) * 4);
@@ -504,34 +524,43 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
                 dst[nb] = sum;
             }
         };
-        if (MODE == SK_QKV && t == 0) {
-            f4 pr[2][NBP];
-            gather(0, pr[0]);
-            gather(KS, pr[1]);
-            skinny_store<2, MODE, NBP>(a, tile, pr, lane, pre, p * NBP);
+        if (pair_tile) {
+            const int w0 = (t & ~1) * KS;                      // first wave of the PAIRED block's first tile
+            f4 pr[2][NBPP];
+            gather(w0, eg0, pr[0]);
+            gather(w0 + KS, eg0, pr[1]);
+            SkPre<NBPP> pp2;
+#pragma unroll
+            for (int nb = 0; nb < NBPP; ++nb) {
+                pp2.pos[nb] = pre.pos[nb];
+                pp2.page[nb] = pre.page[nb];
+            }
+            load_rstd(pp2, eg0);
+            skinny_store<2, MODE, NBPP>(a, tile & ~1, pr, lane, pp2, eg0);
             return;
         }
-        f4 one[1][NBP];
-        gather(t * KS, one[0]);
+        f4 one[1][NBPV];
+        gather(t * KS, eg0, one[0]);
         if (split) {                                           // split-K partial, lane-linear: one 16-byte store per lane and column group
 #pragma unroll
-            for (int nb = 0; nb < NBP; ++nb)
-                if (p * NBP + nb < NB) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + p * NBP + nb) * 64 + lane) * 4) = one[0][nb];
+            for (int nb = 0; nb < NBPV; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = one[0][nb];
             return;
         }
-        skinny_store<1, MODE, NBP>(a, tile, one, lane, pre, p * NBP);
+        load_rstd(pre, eg0);
+        skinny_store<1, MODE, NBPV>(a, tile, one, lane, pre, eg0);
         return;
     }
-    // KS == 1: the wave holds the whole K sum of its tile (NBP == NB)
+    // KS == 1 (not SK_QKV): the wave holds the whole K sum of its tile and finishes it alone (NBPV == NB, eg0 == 0)
     if (split) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
         return;
     }
-    f4 one[1][NBP];
+    f4 one[1][NBPV];
 #pragma unroll
-    for (int nb = 0; nb < NBP; ++nb) one[0][nb] = acc[nb];
-    skinny_store<1, MODE, NBP>(a, tile, one, lane, pre);
+    for (int nb = 0; nb < NBPV; ++nb) one[0][nb] = acc[nb];
+    load_rstd(pre, 0);
+    skinny_store<1, MODE, NBPV>(a, tile, one, lane, pre);
 }
 
 // second stage of the split-K SK_ROW projection: y = sum_s part[s] (s ascending: fixed order), then the residual epilogue.
@@ -559,8 +588,9 @@ static int g_skx_cus = 256;
 
 template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
 static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid, hipStream_t s) {
-    constexpr int lds = NBUF * KC * NB * 1024;
-    static_assert(lds >= T_MAX * KS * NB * 1024, "the reduction scratch lives inside the x ring");
+    constexpr int ring = NBUF * KC * NB * 1024;
+    constexpr int lds = ring + AUR_MAX_BATCH * 4;              // + 1/rms per batch row
+    static_assert(ring >= T_MAX * KS * NB * 1024, "the reduction scratch lives inside the x ring");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL>,
@@ -575,34 +605,53 @@ static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid
 template <int NB>
 static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s) {
     // chunk depth by column groups: the x ring is NBUF x KC x NB KiB of LDS.  Up to 4 groups (64 rows) KC = 8 (fewest barriers:
-    // 21.6 vs 25.4 us on the QKV shape against KC = 4); 5-8 groups (128 rows) KC = 4 keeps the ring at 128 KiB.
+    // 21.6 vs 25.4 us on the QKV shape against KC = 4); 5-8 groups (128 rows): 2 x 8 ("ring", default) or 4 x 4 k32 tiles - 128 KiB.
     constexpr int KC = NB <= 4 ? 8 : 4;
     constexpr int KCR = NB <= 4 ? 6 : 3, NBUFR = NB <= 4 ? 5 : 4, NLR = NB <= 4 ? 2 : 3;       // split-K residual projection
     const int N16 = a.Npad >> 4;
     SkxGeom gm{};
     gm.S = 1;
     gm.part = part;
-    auto split = [&](int tmax) {                               // N16 tiles over min(N16, max(#CUs, ceil(N16 / tmax))) workgroups
+    // half grid (a.half_grid, 5-8 column groups): the launch is meant for a stream that owns HALF of the CUs (the decode stream while a
+    // front end runs on the other half): half as many workgroups with twice the tiles each, so that a CU streams x through its LDS
+    // once instead of once per round of workgroups (QKV 62 -> 39 us, gate/up 77 -> 58 us on 16 CUs per XCD, tools/gemv_lab).  Same
+    // k phases per tile, same summation order: bitwise the full-grid result.
+    const bool half = a.half_grid && NB > 4;
+    auto split = [&](int tmax, int cus) {                      // N16 tiles over min(N16, max(cus, ceil(N16 / tmax))) workgroups
         int G = (N16 + tmax - 1) / tmax;
-        if (G < g_skx_cus) G = N16 < g_skx_cus ? N16 : g_skx_cus;
+        if (G < cus) G = N16 < cus ? N16 : cus;
         gm.tiles_lo = N16 / G;
         gm.n_hi = N16 % G;
         return G;
     };
     switch (a.mode) {
         case SK_QKV: {
-            // workgroup c: PAIRED block c of the Q / K region + V tile c (equal counts by construction: q_cols == k_cols == V cols)
+            // unit c = PAIRED block c of the Q / K region + V tile c (equal counts by construction: q_cols == k_cols == V cols);
+            // a workgroup owns unit c (full grid) or units c and c + pairs / 2 (half grid).  2 k phases per tile: 31.0 us against
+            // 35.5 us with 4 at 128 rows, 22.7 vs 23.1 at 64 (tools/gemv_lab) - and 6 tiles x 2 phases still fit one workgroup.
             const int pairs = (a.q_cols + a.k_cols) >> 5;
             gm.v_tile0 = (a.q_cols + a.k_cols) >> 4;
             if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
-            if (NB > 4 && a.ring == 1) return launch_skx_t<3, 4, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
-            if (a.waves == 2) return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 2, 4>(a, gm, dim3(pairs, 1), s);
-            return launch_skx_t<3, 4, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
+            if constexpr (NB > 4) {
+                if (half && (pairs & 1) == 0) return launch_skx_t<6, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs / 2, 1), s);
+                if (a.ring == 1) return launch_skx_t<3, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
+            }
+            return launch_skx_t<3, 2, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
         case SK_SILU_MUL:
-            if (NB > 4 && a.ring == 1) return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 2, 4, 4>(a, gm, dim3(split(6), 1), s);
-            return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6), 1), s);
-        case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, KC, 4, 4, 4>(a, gm, dim3(split(8), 1), s);
+            // engines of more than 64 slots (a.gu_ks == 1): ONE k phase per tile, so that the half grid's 11 tiles per workgroup fit
+            // (128 rows: full grid 51.0 us against 49.5 with 2 phases, half grid on 16 CUs per XCD 58 against 77; 64 rows 35.5 vs 33.4).
+            // A constant of the engine, never of the live batch: results stay batch-invariant.
+            if (a.gu_ks == 1) {
+                if constexpr (NB > 4) {
+                    if (half) return launch_skx_t<11, 1, SK_SILU_MUL, NB, 4, 4, 4, 4>(a, gm, dim3(split(11, g_skx_cus / 2), 1), s);
+                    if (a.ring == 1) return launch_skx_t<6, 1, SK_SILU_MUL, NB, 8, 2, 8, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+                }
+                return launch_skx_t<6, 1, SK_SILU_MUL, NB, KC, 4, 8, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+            }
+            if (NB > 4 && a.ring == 1) return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 2, 4, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+            return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+        case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, KC, 4, 4, 4>(a, gm, dim3(split(8, g_skx_cus), 1), s);
         case SK_ROW: {
             // split-K 4: 4 tiles x 3 k phases per workgroup, N16 / 4 n-blocks x 4 k splits (= 256 workgroups at N = 4096)
             gm.S = 4;

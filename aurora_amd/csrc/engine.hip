@@ -72,10 +72,11 @@ struct aur_ctx {
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
+    int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
     // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
     // that one batch can decode on one stream while the next batch's ViT + prefill run on another.  The members above
@@ -87,7 +88,7 @@ struct aur_ctx {
         int32_t *s_pos, *s_ids, *s_len, *s_fin;
         const int32_t* ptab;
         int batch = 0, max_new = 0, eos = -1;
-        hipGraphExec_t graph = nullptr;
+        hipGraphExec_t graph = nullptr, graph_h = nullptr;
         int graph_batch = 0;
     } banks[2];
     int nbanks = 1, cur_bank = 0;
@@ -299,8 +300,11 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
 extern "C" void aur_destroy(aur_ctx* ctx) {
     if (!ctx) return;
     ctx->banks[ctx->cur_bank].graph = ctx->graph;
-    for (auto& K : ctx->banks)
+    ctx->banks[ctx->cur_bank].graph_h = ctx->graph_h;
+    for (auto& K : ctx->banks) {
         if (K.graph) (void)hipGraphExecDestroy(K.graph);
+        if (K.graph_h) (void)hipGraphExecDestroy(K.graph_h);
+    }
     for (auto& kv : ctx->timers) {
         if (kv.second.e0) (void)hipEventDestroy(kv.second.e0);
         if (kv.second.e1) (void)hipEventDestroy(kv.second.e1);
@@ -790,17 +794,22 @@ static KvLayout llm_kv(const aur_ctx* c, int layer) {
     return L;
 }
 
+static void drop_graphs(aur_ctx* ctx) {
+    if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
+    if (ctx->graph_h) (void)hipGraphExecDestroy(ctx->graph_h);
+    ctx->graph = ctx->graph_h = nullptr;
+}
+
 extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t eos_id, void* stream) {
     if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_begin_batch: language weights not finalized");
     const aur_config& g = ctx->cfg;
     if (batch < 1 || batch > g.max_batch) return aur_fail(ctx, AUR_ERR_ARG, "batch %d outside [1, %d]", batch, g.max_batch);
     if (max_new_tokens < 1 || max_new_tokens > g.max_new_tokens) return aur_fail(ctx, AUR_ERR_ARG, "max_new_tokens %d outside [1, %d]", max_new_tokens, g.max_new_tokens);
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->graph && (ctx->max_new != max_new_tokens || ctx->eos != eos_id || ctx->graph_batch != batch)) {
+    if ((ctx->graph || ctx->graph_h) && (ctx->max_new != max_new_tokens || ctx->eos != eos_id || ctx->graph_batch != batch)) {
         // eos / max_new / batch are by-value kernel arguments frozen inside the captured graph
         CK(hipStreamSynchronize(s));
-        CK(hipGraphExecDestroy(ctx->graph));
-        ctx->graph = nullptr;
+        drop_graphs(ctx);
     }
     ctx->batch = batch;
     ctx->max_new = max_new_tokens;
@@ -954,6 +963,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
     q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.waves = ctx->qkv_depth; q.ring = ctx->skinny_ring;
+    q.half_grid = ctx->decode_half;
     return q;
 }
 static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
@@ -979,6 +989,7 @@ static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
     gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
     gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant; gu.ring = ctx->skinny_ring;
+    gu.gu_ks = g.max_batch > 64 ? 1 : 2; gu.half_grid = ctx->decode_half;
     return gu;
 }
 static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
@@ -1020,22 +1031,20 @@ extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
     stage_begin(ctx, "decode", s);
     const bool use_graph = ctx->cfg.use_graph && !ctx->prof;
     if (use_graph) {
-        if (!ctx->graph || ctx->graph_batch != ctx->batch) {
-            if (ctx->graph) {
-                (void)hipGraphExecDestroy(ctx->graph);
-                ctx->graph = nullptr;
-            }
+        if (ctx->graph_batch != ctx->batch) drop_graphs(ctx);
+        hipGraphExec_t& gx = ctx->decode_half ? ctx->graph_h : ctx->graph;
+        if (!gx) {
             hipGraph_t gr;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             int rc = enqueue_decode_step(ctx, s, false);
             hipError_t e = hipStreamEndCapture(s, &gr);
             if (rc) return rc;
             if (e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            CK(hipGraphInstantiate(&ctx->graph, gr, nullptr, nullptr, 0));
+            CK(hipGraphInstantiate(&gx, gr, nullptr, nullptr, 0));
             (void)hipGraphDestroy(gr);
             ctx->graph_batch = ctx->batch;
         }
-        for (int i = 0; i < steps; ++i) CK(hipGraphLaunch(ctx->graph, s));
+        for (int i = 0; i < steps; ++i) CK(hipGraphLaunch(gx, s));
     } else {
         for (int i = 0; i < steps; ++i) {
             int rc = enqueue_decode_step(ctx, s, ctx->prof);
@@ -1126,11 +1135,13 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
+    } else if (!strcmp(name, "decode_half_grid")) {
+        // the following aur_llm_decode calls go to a stream that owns half of the CUs: QKV / gate-up launch half as many workgroups
+        // with twice the tiles (decode.hip launch_skx_nb); bitwise the same tokens.  Keeps both captured graphs.
+        ctx->decode_half = value ? 1 : 0;
+        return AUR_OK;
     } else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
-    if (ctx->graph) {             // kernel arguments are frozen in the captured graph
-        (void)hipGraphExecDestroy(ctx->graph);
-        ctx->graph = nullptr;
-    }
+    drop_graphs(ctx);             // kernel arguments are frozen in the captured graphs
     return AUR_OK;
 }
 
@@ -1185,11 +1196,11 @@ extern "C" int aur_select_bank(aur_ctx* ctx, int32_t bank) {
     if (bank < 0 || bank >= ctx->nbanks) return aur_fail(ctx, AUR_ERR_ARG, "bank %d outside [0, %d) (aur_config.num_banks)", bank, ctx->nbanks);
     if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_select_bank: workspace not set");
     aur_ctx::Bank& o = ctx->banks[ctx->cur_bank];
-    o.batch = ctx->batch; o.max_new = ctx->max_new; o.eos = ctx->eos; o.graph = ctx->graph; o.graph_batch = ctx->graph_batch;
+    o.batch = ctx->batch; o.max_new = ctx->max_new; o.eos = ctx->eos; o.graph = ctx->graph; o.graph_h = ctx->graph_h; o.graph_batch = ctx->graph_batch;
     const aur_ctx::Bank& K = ctx->banks[bank];
     ctx->cur_bank = bank;
     ctx->d_x = K.d_x; ctx->s_ssq_mlp = K.s_ssq_mlp; ctx->s_ssq_attn = K.s_ssq_attn; ctx->d_logits = K.d_logits;
     ctx->s_pos = K.s_pos; ctx->s_ids = K.s_ids; ctx->s_len = K.s_len; ctx->s_fin = K.s_fin; ctx->ptab_cur = K.ptab;
-    ctx->batch = K.batch; ctx->max_new = K.max_new; ctx->eos = K.eos; ctx->graph = K.graph; ctx->graph_batch = K.graph_batch;
+    ctx->batch = K.batch; ctx->max_new = K.max_new; ctx->eos = K.eos; ctx->graph = K.graph; ctx->graph_h = K.graph_h; ctx->graph_batch = K.graph_batch;
     return AUR_OK;
 }

@@ -59,6 +59,10 @@ def parse():
     p.add_argument("--overlap-steps", type=int, default=-1,
                    help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
                         "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
+    p.add_argument("--half-grid", action="store_true",
+                   help="--overlap 1 A/B: masked decode steps launch the QKV / gate-up projections with half as many workgroups and twice the "
+                        "tiles each (decode_half_grid; 43 vs 62 us and 49 vs 63 us alone on 16 CUs per XCD, but 13.66 vs 13.72 captions/s "
+                        "next to a running front end: the contended resource is bandwidth, not the x re-reads)")
     p.add_argument("--sync-chunks", action="store_true",
                    help="--overlap 1: synchronise the decode stream after every chunk (profiling aid: rocprofv3 --kernel-trace needs the "
                         "queue of pending hipGraph launches kept short; costs a host round trip per chunk)")
@@ -407,6 +411,7 @@ def main():
             #      sequences B .. B + G - 1, and at the group's boundary aur_llm_prefill_commit (decode stream) exchanges page-table
             #      rows and produces the first tokens.  The first `k_masked` decode steps of a chunk run on the complementary
             #      mask (the front end is in flight), the rest unmasked.
+            half_grid = 1 if args.half_grid else 0
             k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, int(round(0.8 * (S // NG))))
             sD = torch.cuda.current_stream()
             sF = masked[0]
@@ -444,7 +449,9 @@ def main():
                     if k1 > 0:
                         sDm.wait_event(e1)
                         with torch.cuda.stream(sDm):
+                            eng.set_option("decode_half_grid", half_grid)   # half as many workgroups, twice the tiles each
                             eng.decode(k1)
+                            eng.set_option("decode_half_grid", 0)
                             evm = torch.cuda.Event()
                             evm.record(sDm)
                         sD.wait_event(evm)

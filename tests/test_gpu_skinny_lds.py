@@ -104,3 +104,29 @@ def test_batch_invariance_and_graph_at_two_to_eight_column_groups(B):
             if (top2[0] - top2[1]).item() <= 2 * LOGIT_TOL * scale:
                 break
             assert a == b, (i, j)
+
+
+@pytest.mark.parametrize("B", [70, 128])
+def test_half_grid_decode_is_bitwise_the_full_grid_decode(B):
+    """`decode_half_grid` (the decode stream owns half of the CUs while a front end runs on the other half): the QKV and gate/up
+    projections launch half as many workgroups with twice the tiles each.  Same k phases per tile, same summation order: the
+    tokens AND the logits must equal the full-grid ones bit for bit, with steps of the two kinds interleaved."""
+    cfg = LLM_CFGS["hd64"]
+    gen = torch.Generator().manual_seed(100 + B)
+    lens = [33 + (5 * i) % 70 for i in range(B)]
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
+    eng, w = lds_engine(cfg, 9, B)
+    try:
+        full = eng.generate([padded(e) for e in embs], lens, 12, eos_id=None)
+        lg_full = eng.logits().clone()
+        eng.begin_batch(B, 12, None)
+        for b in range(B):
+            eng.prefill(b, padded(embs[b]), lens[b])
+        for i in range(11):
+            eng.set_option("decode_half_grid", i % 2)          # alternate: both captured graphs, one shared decode state
+            eng.decode(1)
+        eng.set_option("decode_half_grid", 0)
+        assert eng.outputs() == full
+        assert torch.equal(eng.logits(), lg_full)
+    finally:
+        eng.close()

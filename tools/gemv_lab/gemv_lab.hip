@@ -544,9 +544,17 @@ static void launch_skf(dim3 grid, const Args& a, hipStream_t st) {
     hipLaunchKernelGGL((skf_kernel<T_MAX, KS, KC, NBUF, U, NL, NB>), grid, dim3(64 * (T_MAX * KS + NL)), lds, st, a);
 }
 
+static int g_mask_cus = 0;          // > 0: run everything on a stream restricted to this many CUs of every XCD
+
 template <int NB>
 static void lab(int iters, const char* only) {
     hipStream_t st;
+    if (g_mask_cus > 0) {
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 256; ++i)
+            if (i / 8 < g_mask_cus) m[i >> 5] |= 1u << (i & 31);
+        CKH(hipExtStreamCreateWithCUMask(&st, 8, m));
+    } else
     CKH(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CKH(hipEventCreate(&e0));
@@ -643,6 +651,17 @@ static void lab(int iters, const char* only) {
             if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL8", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 8, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
         } else if (nm == "qkv") {
             run("skx T3 KS4 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<3, 4, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            if constexpr (NB > 4) {
+                run("skx T3 KS4 KC8 NBUF2 U2 (256 wg, engine ring)", [&](int cp) { launch_skx<3, 4, 8, 2, 2, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+                run("skx T3 KS2 KC8 NBUF2 U4 (256 wg)", [&](int cp) { launch_skx<3, 2, 8, 2, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+                run("skx T3 KS2 KC8 NBUF2 U2 (256 wg)", [&](int cp) { launch_skx<3, 2, 8, 2, 2, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+                run("skx T6 KS2 KC8 NBUF2 U4 (128 wg)", [&](int cp) { launch_skx<6, 2, 8, 2, 4, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 6, 0), st); }, true, 0);
+                run("skx T6 KS2 KC8 NBUF2 U2 (128 wg)", [&](int cp) { launch_skx<6, 2, 8, 2, 2, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 6, 0), st); }, true, 0);
+            }
+            run("skx T3 KS2 dma NBUF4 U8 NL4 (256 wg)", [&](int cp) { launch_skx<3, 2, KC, 4, 8, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T3 KS2 dma NBUF4 U4 NL4 (256 wg)", [&](int cp) { launch_skx<3, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
+            run("skx T6 KS2 dma NBUF4 U4 NL4 (128 wg)", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 6, 0), st); }, true, 0);
+            run("skx T6 KS2 dma NBUF4 U8 NL4 (128 wg)", [&](int cp) { launch_skx<6, 2, KC, 4, 8, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 6, 0), st); }, true, 0);
             run("skf T3 KS4 flags KCx NBUF4 U4 NL4", [&](int cp) { launch_skf<3, 4, KC, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
             run("skf T3 KS4 flags KC4 NBUF4 U4 NL4", [&](int cp) { launch_skf<3, 4, 4, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
             run("skf T3 KS4 flags KC4 NBUF(8|4) U4 NL4", [&](int cp) { launch_skf<3, 4, 4, (NB <= 4 ? 8 : 4), 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
@@ -658,6 +677,17 @@ static void lab(int iters, const char* only) {
             run("skx T3 KS4 reg R2 U4 NL4 KC8", [&](int cp) { launch_skx<3, 4, 8, 3, 4, 0, 4, NB, 1>(dim3(256, 1), mk(cp, out, 1, 3, 0), st); }, true, 0);
         } else if (nm == "gateup") {
             run("skx T6 KS2 dma NBUF4 U4 NL4 (shipped)", [&](int cp) { launch_skx<6, 2, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            if constexpr (NB > 4) {
+                run("skx T6 KS2 KC8 NBUF2 U4 (256 wg, engine ring)", [&](int cp) { launch_skx<6, 2, 8, 2, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+                run("skx T6 KS1 KC8 NBUF2 U4 (256 wg)", [&](int cp) { launch_skx<6, 1, 8, 2, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+                run("skx T6 KS1 KC8 NBUF2 U8 (256 wg)", [&](int cp) { launch_skx<6, 1, 8, 2, 8, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+                run("skx T11 KS1 KC8 NBUF2 U4 (128 wg)", [&](int cp) { launch_skx<11, 1, 8, 2, 4, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 10, 96), st); }, true, 0);
+                run("skx T11 KS1 KC4 NBUF4 U2 (128 wg)", [&](int cp) { launch_skx<11, 1, 4, 4, 2, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 10, 96), st); }, true, 0);
+            }
+            run("skx T6 KS1 dma NBUF4 U8 NL4 (256 wg)", [&](int cp) { launch_skx<6, 1, KC, 4, 8, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T6 KS1 dma NBUF4 U4 NL4 (256 wg)", [&](int cp) { launch_skx<6, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
+            run("skx T11 KS1 dma NBUF4 U4 NL4 (128 wg)", [&](int cp) { launch_skx<11, 1, KC, 4, 4, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 10, 96), st); }, true, 0);
+            run("skx T11 KS1 dma NBUF4 U8 NL4 (128 wg)", [&](int cp) { launch_skx<11, 1, KC, 4, 8, 0, 4, NB, 0>(dim3(128, 1), mk(cp, out, 1, 10, 96), st); }, true, 0);
             run("skf T6 KS2 flags KCx NBUF4 U4 NL4", [&](int cp) { launch_skf<6, 2, KC, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
             run("skf T6 KS2 flags KC4 NBUF4 U4 NL4", [&](int cp) { launch_skf<6, 2, 4, 4, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
             run("skf T6 KS2 flags KC2 NBUF8 U4 NL4", [&](int cp) { launch_skf<6, 2, 2, 8, 4, 4, NB>(dim3(256, 1), mk(cp, out, 1, 5, 96), st); }, true, 0);
@@ -680,6 +710,8 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 96;
     const char* only = argc > 2 ? argv[2] : "";
     const int nb = argc > 3 ? atoi(argv[3]) : 0;            // column groups: 4 (64 rows), 8 (128 rows); 0 = both
+    g_mask_cus = argc > 4 ? atoi(argv[4]) : 0;
+    if (g_mask_cus > 0) printf("==== stream restricted to %d CUs of every XCD\n", g_mask_cus);
     if (nb == 0 || nb == 4) { printf("---- 64 rows\n"); lab<4>(iters, only); }
     if (nb == 0 || nb == 8) { printf("---- 128 rows\n"); lab<8>(iters, only); }
     return 0;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--nseq", type=int, default=1, help="sequences per prefill pass for the pre_* kernels (<= batch)")
+    ap.add_argument("--half-grid", action="store_true", help="decode projections with half as many workgroups (decode_half_grid)")
     ap.add_argument("--mask-cus", type=int, default=0, help="time the kernels on a stream restricted to this many CUs of every XCD")
     args = ap.parse_args()
     from aurora_amd import synthetic as S
@@ -46,6 +47,8 @@ def main():
         from aurora_amd.streams import cu_masked_stream
         torch.cuda.set_stream(cu_masked_stream(args.mask_cus, from_top=True))
         eng.set_option("gemm_max_wgs", 8 * args.mask_cus)
+    if args.half_grid:
+        eng.set_option("decode_half_grid", 1)
     eng.set_option("microbench_prefill_nseq", min(args.nseq, B))
     M = _rup(L0, 32) * min(args.nseq, B)
     kv_bytes = B * (L0 + 1) * 2 * d * 2
