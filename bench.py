@@ -55,7 +55,7 @@ def parse():
     p.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1],
                    help="continuous mode: 1 = a group's next front end (ViT + splice + staged prefill into spare KV sequences) runs on its own "
                         "CU-masked stream WHILE all slots decode, and is committed at the group's boundary; 0 = front ends between decode chunks "
-                        "(11.4 captions/s against 13.2-13.3 with 1 on one MI355X); -1 = auto (1 whenever the continuous mode applies)")
+                        "(11.4 captions/s against 13.6-13.7 with 1 on one MI355X); -1 = auto (1 whenever the continuous mode applies)")
     p.add_argument("--overlap-steps", type=int, default=-1,
                    help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
                         "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
