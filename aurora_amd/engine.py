@@ -124,6 +124,11 @@ class AuroraCapEngine:
             torch.cuda.synchronize()
             self.L.aur_destroy(self.ctx)
             self.ctx = None
+            for pair in getattr(self, "_masked", {}).values():      # CU-masked streams of caption_stream(overlap=True)
+                for st in pair:
+                    from .streams import destroy_stream
+                    destroy_stream(st)
+            self._masked = {}
             if torch.cuda.current_stream(self.dev) == self.stream:
                 torch.cuda.set_stream(self._prev_stream)
 

@@ -22,6 +22,8 @@ def _runtime():
         _hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # torch's copy: one runtime per process
         _hip.hipExtStreamCreateWithCUMask.restype = C.c_int
         _hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        _hip.hipStreamDestroy.restype = C.c_int
+        _hip.hipStreamDestroy.argtypes = [C.c_void_p]
     return _hip
 
 
@@ -38,8 +40,13 @@ def cu_mask_words(cus_per_xcd: int, from_top: bool = False, xcds: int = 8, cus_i
     return words
 
 
+def destroy_stream(stream: "torch.cuda.ExternalStream") -> None:
+    """Release a stream made by `cu_masked_stream` (the wrapper does not own it).  The caller has synchronised it."""
+    _runtime().hipStreamDestroy(C.c_void_p(stream.cuda_stream))
+
+
 def cu_masked_stream(cus_per_xcd: int, from_top: bool = False, device=None) -> "torch.cuda.ExternalStream":
-    """A new HIP stream whose kernels run on `cus_per_xcd` CUs of every XCD only (it lives as long as the process)."""
+    """A new HIP stream whose kernels run on `cus_per_xcd` CUs of every XCD only (release it with `destroy_stream`)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     words = cu_mask_words(cus_per_xcd, from_top)
     arr = (C.c_uint32 * len(words))(*words)

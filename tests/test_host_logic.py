@@ -171,3 +171,22 @@ def test_lmms_adaptor_provides_the_accelerator_calls_world2():
         p.join(60)
         assert p.exitcode == 0
     assert got == [(0, 2, [3, 4]), (1, 2, [3, 4])]
+
+
+def test_cu_mask_words_enable_k_cus_of_every_xcd():
+    """aurora_amd/streams.py: the driver deals mask bit i to CU i // 8 of XCD i % 8, so "k CUs of every XCD" is bits with
+    i // 8 < k (or >= 32 - k from the top); the two ends must be complementary when they add up to 32."""
+    from aurora_amd.streams import cu_mask_words
+    lo, hi = cu_mask_words(16), cu_mask_words(16, from_top=True)
+    assert len(lo) == 8 and all(w == 0xFFFFFFFF for w in lo[:4]) and all(w == 0 for w in lo[4:])
+    assert [a ^ b for a, b in zip(lo, hi)] == [0xFFFFFFFF] * 8 and [a & b for a, b in zip(lo, hi)] == [0] * 8
+    for k in (4, 12, 20, 32):
+        bits = [i for i in range(256) if cu_mask_words(k)[i >> 5] >> (i & 31) & 1]
+        assert len(bits) == 8 * k and all(i // 8 < k for i in bits)
+        for xcd in range(8):
+            assert sum(1 for i in bits if i % 8 == xcd) == k
+    import pytest
+    with pytest.raises(ValueError):
+        cu_mask_words(0)
+    with pytest.raises(ValueError):
+        cu_mask_words(33)
