@@ -74,7 +74,7 @@ struct aur_ctx {
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
-    int skinny_variant = 0, row_split_min_k = 8192, qkv_depth = 4, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
+    int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
@@ -962,7 +962,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.waves = ctx->qkv_depth; q.ring = ctx->skinny_ring;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.ring = ctx->skinny_ring;
     q.half_grid = ctx->decode_half;
     return q;
 }
@@ -1122,7 +1122,6 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
-    else if (!strcmp(name, "skinny_qkv_depth")) ctx->qkv_depth = (int)value;
     else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;

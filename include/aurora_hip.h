@@ -195,10 +195,12 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
- * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_qkv_depth", "skinny_ring",
- * "microbench_prefill_nseq" sequences per pass for the pre_* microbenchmarks.  Every knob is state of THIS ctx.  The gemm_*
- * knobs are bit-neutral; the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not
- * bit-comparable across settings). */
+ * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_ring", "gemm_tile_order" 1 (rounds of the persistent grid are
+ * compact tile blocks shared by the XCDs) / 0 (per-XCD tile ranges), "microbench_prefill_nseq" sequences per pass for the pre_*
+ * microbenchmarks.  "decode_half_grid" 1 / 0 does NOT invalidate the graphs (one is kept per setting): the next aur_llm_decode
+ * calls go to a stream that owns half of the CUs, so the QKV / gate-up projections launch half as many workgroups with twice the
+ * tiles each - bitwise the same tokens.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;
+ * the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
 /* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
  * kernel in {dec_norm, dec_qkv, dec_attn, dec_o, dec_gateup, dec_down, dec_lm_head, pre_norm, pre_qkv, pre_attn,

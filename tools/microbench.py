@@ -75,9 +75,6 @@ def main():
         eng.set_option("skinny_variant", variant)
         run(tag, dec)
     eng.set_option("skinny_variant", 1)
-    eng.set_option("skinny_qkv_depth", 2)
-    run("x-through-LDS qkv depth 2", ["dec_qkv"])
-    eng.set_option("skinny_qkv_depth", 4)
     if B > 64:
         eng.set_option("skinny_ring", 1)
         run("x-through-LDS ring 2 x 8", ["dec_qkv", "dec_gateup"])
