@@ -135,8 +135,11 @@ def test_caption_stream_continuous_batching():
         eng.close()
 
 
-def test_stream_and_adaptor_against_the_oracle_with_eos():
-    """f2 / f3 against the ORACLE, not against the engine itself: continuous batching with EOS stopping
+@pytest.mark.parametrize("spare", [0, 2])
+def test_stream_and_adaptor_against_the_oracle_with_eos(spare):
+    """spare = 2: the same comparison with the next clips' front ends prefetched on a CU-masked stream beside the decode (staged
+    prefill into spare KV sequences, committed into freed slots).
+    f2 / f3 against the ORACLE, not against the engine itself: continuous batching with EOS stopping
     and the lmms-eval adaptor must give each clip the oracle's greedy ids (CPU port of the reference path, fp16-storage
     emulation) up to the first position whose oracle margin is inside the logit tolerance - and stop at the same EOS."""
     from oracle import aurora_oracle as O
@@ -158,7 +161,8 @@ def test_stream_and_adaptor_against_the_oracle_with_eos():
         scale = logits.abs().max().item()
         return all((logits[i].topk(2).values[0] - logits[i].topk(2).values[1]).item() > 2 * TOL * scale for i in range(len(ids)))
 
-    eng = build(max_batch=3, max_new=N)
+    from aurora_amd.engine import AuroraCapEngine
+    eng = AuroraCapEngine(cfg, w, max_frames=4, max_batch=3, max_ctx=512, max_new_tokens=N, spare_slots=spare)
     try:
         got = dict(eng.caption_stream(cs, 0.5, N, eos_id=eos, check_every=4))
         assert sorted(got) == list(range(7))
