@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * sc);
-            m_run[qt] = m_new;
+            // the softmax is VALU-bound (27-31 % MFMA busy, PMC): after the first few key blocks a query's running maximum rarely
+            // moves, and then alpha == 1 exactly - the rescale of l and of the VD16 x 4 output accumulators is skipped for the whole
+            // wave (wave-uniform branch; multiplying by 1.0f is the identity, so the result is bitwise the same)
+            const bool moved = m_new != m_run[qt];
             const float ms = m_use * sc;
             float ps = 0.f;
 #pragma unroll
@@ -170,11 +172,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     ps += p;
                     pf[qt][kt >> 1][(kt & 1) * 4 + i] = (half_t)p;
                 }
-            l_run[qt] = l_run[qt] * alpha + ps;
+            if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_use) * sc);
+                m_run[qt] = m_new;
+                l_run[qt] = l_run[qt] * alpha + ps;
 #pragma unroll
-            for (int d = 0; d < VD16; ++d)
+                for (int d = 0; d < VD16; ++d)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc_o[d][qt][i] *= alpha;
+                    for (int i = 0; i < 4; ++i) acc_o[d][qt][i] *= alpha;
+            } else {
+                l_run[qt] = l_run[qt] + ps;
+            }
         }
 #pragma unroll
         for (int d = 0; d < VD16; ++d)
