@@ -10,11 +10,13 @@ One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
 Workload = BASELINE.json configs[1]: AuroraCap-7B-VID, 8 frames, token_kept_ratio 0.3, 256 new tokens, 1 GPU.
 `value` = captions/sec of the whole job (all ranks), inputs resident in HBM when the timed region starts.
 
-By default the stages of a step run strictly one after another.  `--pipeline` software-pipelines steps on two HIP
-streams and two generation banks (KV slots + per-batch state): while batch i decodes (HBM-bound) the front end (ViT +
-prefill, MFMA-bound) of batch i+1 runs; the timed region then executes exactly K front ends and K decodes (the
-pipeline is primed during warm-up), i.e. the full work of K steps.  Measured gain on MI355X is only 2-3 % (the two
-kernel classes contend for CUs / LDS) at +37 % p50 TTFT, so it is opt-in.
+Default schedule: steady-state continuous batching over `--batch` KV slots (128).  All slots decode all the time; they form
+batch / G groups (G = `--prefill-group`, 4) whose captions end group by group; the front end of a group's next clips (ViT + ToMe +
+splice + staged prefill into spare KV sequences) runs on its own stream restricted to 16 CUs of every XCD WHILE the slots decode
+(decode is HBM-bound, the front end MFMA-bound), and is committed into the group's slots at its boundary.  One step = one cycle of
+max_new_tokens - 1 decode steps = `batch` captions completed + `batch` front ends.  Every cycle's ids are checked against one
+batch-mode step.  `--overlap 0` runs the front ends between decode chunks on one stream (reported beside the line as
+`sequential_schedule`), `--batch-mode` times independent batches (`batch_mode`), `--pipeline` is round 1's two-bank variant.
 
 For N > 1 clips shard across ranks (one process per GPU, no data-path collective); the only collective is the RCCL
 all_gather of the generated ids at the end of each step (the reference's gather_object, evaluator.py:519-546).
