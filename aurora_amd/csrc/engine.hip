@@ -73,7 +73,7 @@ struct aur_ctx {
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
-    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
+    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
@@ -132,6 +132,7 @@ static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t
     a.max_wgs = ctx->gemm_max_wgs;
     a.wide_epilogue = ctx->gemm_wide;
     a.tile_order = ctx->gemm_tile_order;
+    a.tail_split = ctx->gemm_tail_split;
     return launch_gemm(a, epi, s);
 }
 
@@ -1128,6 +1129,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
     else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
     else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
 
     else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
     else if (!strcmp(name, "dec_attn_pps")) {

@@ -248,8 +248,7 @@ hipError_t gemm_init() {
 }
 
 
-hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if ((a.gemm_mode == 1 && gemm256_eligible(a)) || (a.gemm_mode == 2 && (a.Npad & 255) == 0)) return launch_gemm256(a, epi, s);
+static hipError_t launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
     const int nbn = a.Npad / BN, nbm = (a.M + BM - 1) / BM;
     dim3 grid(nbn * nbm), block(256);
     if (epi == EPI_ROW)
@@ -257,6 +256,41 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     else
         hipLaunchKernelGGL(gemm_kernel<EPI_QKV>, grid, block, GEMM_LDS, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+    if (!((a.gemm_mode == 1 && gemm256_eligible(a)) || (a.gemm_mode == 2 && (a.Npad & 255) == 0))) return launch_gemm128(a, epi, s);
+    // Tile quantisation: the persistent 256x256 kernel runs ceil(tiles / G) rounds of G workgroups, and a GEMM of few rounds can
+    // leave most of the last one idle (o / down projection of a 4-clip prefill pass: 544 tiles = 4.25 rounds of 128, 2.1 of 256).
+    // When the last round would be less than ~60 % full, the bottom rows go to the 128x128 kernel instead (a quarter of the work
+    // per tile at ~0.75 of the rate): 4.25 -> ~4.4 rounds' time instead of 5.  Row-wise split, EPI_ROW only (rows carry no position
+    // there); both kernels accumulate every output element over k in the same order, so the result is bit-identical (tested).
+    if (a.tail_split && epi == EPI_ROW) {
+        const int nbn = a.Npad >> 8, nbm = (a.M + 255) >> 8, tiles = nbn * nbm;
+        const int G = a.max_wgs > 0 ? ((a.max_wgs + 7) & ~7) : gemm256_grid_cap();
+        const int full = tiles / G;
+        if (full >= 2 && tiles - full * G > 0) {
+            const int mfull = full * G / nbn;                           // whole M-tile rows that fit `full` rounds
+            const int m0 = mfull * 256;
+            if (m0 > 0 && m0 < a.M) {
+                const int small = ((a.M - m0 + BM - 1) / BM) * (a.Npad / BN);
+                const float t_new = (float)((mfull * nbn + G - 1) / G) + 0.34f * (float)((small + G - 1) / G) + 0.03f;
+                if (t_new + 0.1f < (float)(full + 1)) {
+                    GemmArgs hi = a, lo = a;
+                    hi.M = m0;
+                    lo.M = a.M - m0;
+                    lo.A = a.A + (int64_t)m0 * a.lda;
+                    if (a.out_rows) lo.out_rows = a.out_rows + m0;
+                    else lo.C = a.C + (int64_t)m0 * a.ldc;
+                    if (a.resid) lo.resid = a.resid + (int64_t)m0 * a.ldr;
+                    hipError_t e = launch_gemm256(hi, epi, s);
+                    if (e != hipSuccess) return e;
+                    return launch_gemm128(lo, epi, s);
+                }
+            }
+        }
+    }
+    return launch_gemm256(a, epi, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -346,6 +346,8 @@ hipError_t gemm256_init() {
     return hipSuccess;
 }
 
+int gemm256_grid_cap() { return g_gemm256_cus & ~7; }
+
 bool gemm256_eligible(const GemmArgs& a) {
     // whole 256-column tiles, and enough 256x256 tiles to fill the 256 CUs at one workgroup each
     if (a.Npad & 255) return false;

@@ -32,6 +32,7 @@ struct GemmArgs {
     int gemm_mode;          // 0: 128x128 kernel only, 1: auto, 2: force 256x256 when Npad % 256 == 0
     int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
     int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
+    int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
     int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
@@ -47,6 +48,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 // gemm256.hip: 256x256x64 staggered two-group kernel for large shapes (auto-selected by launch_gemm)
 hipError_t gemm256_init();
 bool gemm256_eligible(const GemmArgs& a);
+int gemm256_grid_cap();           // persistent workgroups of the 256x256 kernel when max_wgs == 0
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
 hipError_t launch_pack_weight(const half_t* w, int n_src, int k_src, int ld_src, const int32_t* row_map, int npad,
                               int kpad, half_t* out, hipStream_t s);

@@ -76,6 +76,7 @@ def parse():
     p.add_argument("--gemm-cus", type=int, default=0,
                    help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
                         "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
+    p.add_argument("--gemm-tail-split", type=int, default=-1, help="A/B: 0 = one 256x256 launch per GEMM, 1 = idle last rounds go to the 128x128 kernel")
     p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--no-graph", action="store_true")
@@ -265,6 +266,8 @@ def main():
         eng.set_option("gemm_max_wgs", args.gemm_cus)
     if args.gemm_tile_order >= 0:
         eng.set_option("gemm_tile_order", args.gemm_tile_order)
+    if args.gemm_tail_split >= 0:
+        eng.set_option("gemm_tail_split", args.gemm_tail_split)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B

@@ -196,7 +196,8 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
  * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_ring", "gemm_tile_order" 1 (rounds of the persistent grid are
- * compact tile blocks shared by the XCDs) / 0 (per-XCD tile ranges), "microbench_prefill_nseq" sequences per pass for the pre_*
+ * compact tile blocks shared by the XCDs) / 0 (per-XCD tile ranges), "gemm_tail_split" 1 (a mostly idle last round of the 256x256
+ * kernel goes to the 128x128 kernel over the bottom rows) / 0, "microbench_prefill_nseq" sequences per pass for the pre_*
  * microbenchmarks.  "decode_half_grid" 1 / 0 does NOT invalidate the graphs (one is kept per setting): the next aur_llm_decode
  * calls go to a stream that owns half of the CUs, so the QKV / gate-up projections launch half as many workgroups with twice the
  * tiles each - bitwise the same tokens.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;

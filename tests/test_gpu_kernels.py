@@ -234,3 +234,30 @@ def test_gemm256_persistent_tiles_bitwise(eng):
     finally:
         eng.set_option("gemm_max_wgs", 0)
         eng.set_option("gemm_mode", 1)
+
+
+def test_gemm_tail_split_is_bitwise_the_single_launch(eng):
+    """A mostly idle last round of the persistent 256x256 kernel is replaced by a 128x128 launch over the bottom rows
+    (gemm.hip launch_gemm): same accumulation order per element, so bias / activation / residual results must not change by a
+    bit - whatever the persistent grid, ragged M included."""
+    from aurora_amd._lib import AUR_ACT_GELU
+    g = torch.Generator().manual_seed(101)
+    m, k, n = 4300, 256, 2048                                        # 17 x 8 = 136 tiles
+    a = (torch.randn(m, k, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, generator=g) * 0.05).half()
+    b = (torch.randn(n, generator=g) * 0.1).half()
+    res = torch.randn(m, n, generator=g).half()
+    eng.set_option("gemm_mode", 2)
+    try:
+        for wgs in (64, 32, 128, 0):                                 # 2.1 rounds of 64, 4.25 of 32, 1.06 of 128, one tile per CU
+            eng.set_option("gemm_max_wgs", wgs)
+            outs = {}
+            for split in (0, 1):
+                eng.set_option("gemm_tail_split", split)
+                outs[split] = (eng.linear(a, w, b), eng.linear(a, w, b, act=AUR_ACT_GELU), eng.linear(a, w, b, resid=res))
+            for x, y in zip(outs[0], outs[1]):
+                assert torch.equal(x, y), wgs
+    finally:
+        eng.set_option("gemm_tail_split", 1)
+        eng.set_option("gemm_max_wgs", 0)
+        eng.set_option("gemm_mode", 1)
