@@ -601,8 +601,19 @@ class AuroraCapEngine:
                         reusable[seq] = evc
                         free_seqs.append(seq)
                         owner[s] = idx
-                # 2. prepare the next clips into every free spare sequence (front-end stream: runs beside the decode below)
-                enqueued = False
+                # 2. one decode chunk, enqueued BEFORE the next front ends (a few hundred launches on the host: the decode must not
+                #    sit behind them); while a front end will be in flight its first part runs on the complementary CU mask
+                decoding = any(o is not None for o in owner)
+                if decoding:
+                    k1 = min(check_every, k_masked) if (free_seqs and not exhausted) else 0
+                    if k1 > 0:
+                        sDm.wait_stream(sD)
+                        with torch.cuda.stream(sDm):
+                            self.decode(k1)
+                        sD.wait_stream(sDm)
+                    if check_every - k1 > 0:
+                        self.decode(check_every - k1)
+                # 3. prepare the next clips into every free spare sequence (front-end stream: runs beside the decode above)
                 while free_seqs and not exhausted:
                     nxt = next(it, None)
                     if nxt is None:
@@ -621,25 +632,15 @@ class AuroraCapEngine:
                             ev = torch.cuda.Event()
                             ev.record(sF)
                         staged.append((idx, seq, emb, L, ev))
-                        enqueued = True
                     except (ValueError, IndexError, AssertionError, _lib.AuroraHipError) as e:
                         free_seqs.append(seq)
                         if on_error is None:
                             raise
                         on_error(idx, e)
-                if all(o is None for o in owner):
+                if not decoding:
                     if not staged:
                         return
                     continue                                      # nothing decoding yet: commit what was just prepared
-                # 3. one decode chunk: while a front end is in flight its first part runs on the complementary CU mask
-                k1 = min(check_every, k_masked) if enqueued else 0
-                if k1 > 0:
-                    sDm.wait_stream(sD)
-                    with torch.cuda.stream(sDm):
-                        self.decode(k1)
-                    sD.wait_stream(sDm)
-                if check_every - k1 > 0:
-                    self.decode(check_every - k1)
                 lens, fin = self.slot_state()
                 done = [s for s in range(B) if owner[s] is not None and fin[s]]
                 if done:

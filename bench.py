@@ -447,8 +447,8 @@ def main():
                     e1.record(sD)
                     if timed:
                         lat_ev.append((e0, e1))
-                    sF.wait_event(e1)
-                    pending[0] = front_async((g + 1) % NG)
+                    # the chunk's decode is enqueued BEFORE the next front end (a few hundred launches on the host): both wait for
+                    # the commit only, and the decode must never sit behind the host's enqueue time
                     n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
                     k1 = min(n, k_masked) if sDm is not None else 0
                     if k1 > 0:
@@ -462,6 +462,8 @@ def main():
                         sD.wait_event(evm)
                     if n - k1 > 0:
                         eng.decode(n - k1)
+                    sF.wait_event(e1)
+                    pending[0] = front_async((g + 1) % NG)
                     if args.sync_chunks:
                         sD.synchronize()
                 got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
