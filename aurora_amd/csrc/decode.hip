@@ -925,7 +925,14 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecAttnArgs a) {
 // Variant 1: software-pipelined over 64-token pages.  While page p is being reduced (QK^T -> softmax -> PV),
 // its V fragments and page p+1's K fragments are already in flight (32 KiB per wave), so a wave never
 // idles for a full HBM round trip between its MFMA bursts.  Requires page_tokens == 64.
-template <int KBLK, int VD16>
+// NT = true: non-temporal loads (the product path); false = default cache policy (lab: does the KV stream evict what the front
+// end's GEMMs keep in L2 / the memory-side cache?  tools/cumask/contention_lab.py, DecAttnArgs.variant == 2)
+template <bool NT>
+__device__ __forceinline__ h8 kv_load(const half_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const h8*)p);
+    else return *(const h8*)p;
+}
+template <int KBLK, int VD16, bool NT = true>
 __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
     const int lane = threadIdx.x;
     const int g = lane >> 4;
@@ -955,18 +962,18 @@ __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
     if (p_first < p_last) {
         const half_t* page = kv_page(kv, seq, p_first * 64);
 #pragma unroll
-        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
+        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = kv_load<NT>(page + koff + i * AUR_FRAG_HALVES);
     }
     for (int p = p_first; p < p_last; ++p) {
         const half_t* page = kv_page(kv, seq, p * 64);
         h8 vf[VD16 * 2];
 #pragma unroll
-        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
+        for (int i = 0; i < VD16 * 2; ++i) vf[i] = kv_load<NT>(page + voff + i * AUR_FRAG_HALVES);
         const bool more = p + 1 < p_last;                 // wave-uniform
         if (more) {
             const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
 #pragma unroll
-            for (int i = 0; i < 4 * KBLK; ++i) kn[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
+            for (int i = 0; i < 4 * KBLK; ++i) kn[i] = kv_load<NT>(pn + koff + i * AUR_FRAG_HALVES);
         }
         const int key0 = p * 64;
         f4 s[4];
@@ -1062,8 +1069,9 @@ __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     if (a.kv.page_tokens & 63) return hipErrorInvalidValue;
     dim3 grid(a.nsplit, a.heads, a.B);
-    const bool pipe = a.variant == 1 && a.kv.page_tokens == 64;
-    if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    const bool pipe = a.variant >= 1 && a.kv.page_tokens == 64;
+    if (a.variant == 2 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8, false>), grid, dim3(64), 0, s, a);
+    else if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_pipe_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_pipe_kernel<1, 2>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_kernel<4, 8>), grid, dim3(64), 0, s, a);
@@ -1074,7 +1082,7 @@ hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
 }
 bool decode_attention_needs_combine(const DecAttnArgs& a) {
     // the pipelined kernel finishes single-split problems itself (see its epilogue)
-    return !(a.nsplit == 1 && a.variant == 1 && a.kv.page_tokens == 64);
+    return !(a.nsplit == 1 && a.variant >= 1 && a.kv.page_tokens == 64);
 }
 hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
     if (!decode_attention_needs_combine(a)) return hipSuccess;

@@ -73,7 +73,7 @@ struct aur_ctx {
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
-    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
+    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
@@ -133,6 +133,7 @@ static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t
     a.wide_epilogue = ctx->gemm_wide;
     a.tile_order = ctx->gemm_tile_order;
     a.tail_split = ctx->gemm_tail_split;
+    a.lab = ctx->gemm_lab;
     return launch_gemm(a, epi, s);
 }
 
@@ -620,6 +621,9 @@ extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frame
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "vit", s);
     const int D = g.vit_hidden;
+    // arrival counters of the ToMe match + select launches: a launch leaves them at zero, but an aborted one (device fault, a
+    // caller that destroyed the stream mid-encode) would not - start every encode from a known state (4 bytes per frame)
+    CK(hipMemsetAsync(ctx->w_tome_cnt, 0, (size_t)g.max_frames * 4, s));
     CK(launch_im2col((const half_t*)pixels, frames, g.vit_channels, height, width, g.vit_patch, ctx->v_kpad, ctx->w_col, s));
     GemmArgs pe{};
     pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * npatch;
@@ -898,13 +902,13 @@ static int prefill_layers(aur_ctx* ctx, int seq0, int nseq, void* embeds, int se
 }
 // First tokens of slots [slot0, slot0 + nseq) from the last prompt rows of `embeds` (the final hidden states `prefill_layers` left
 // there): residual fragments + sum(x^2) - the lm_head applies the (folded) final RMSNorm itself -, logits, argmax, bookkeeping.
-static int prefill_first_tokens(aur_ctx* ctx, int slot0, int nseq, void* embeds, int seq_len, hipStream_t s) {
+static int prefill_first_tokens(aur_ctx* ctx, int slot0, int nseq, void* embeds, int seq_len, hipStream_t s, const char* stage = "prefill") {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden, Mseq = rup(seq_len, 32);
     CK(launch_xfrag_norm((half_t*)embeds + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
     int rc = lm_head_and_advance(ctx, slot0, nseq, 0, seq_len, s);
     if (rc) return rc;
-    stage_end(ctx, "prefill", s);
+    stage_end(ctx, stage, s);
     return AUR_OK;
 }
 
@@ -918,7 +922,11 @@ extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, 
 extern "C" int aur_llm_prefill_stage(aur_ctx* ctx, int32_t seq0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
     if (nseq < 1 || seq0 < 0 || seq0 + nseq > ctx->kv_seqs)
         return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_stage: KV sequences [%d, %d) outside [0, %d) (max_batch + spare_slots)", seq0, seq0 + nseq, ctx->kv_seqs);
-    return prefill_layers(ctx, seq0, nseq, embeds, seq_len, (hipStream_t)stream, "aur_llm_prefill_stage");
+    // its own timer interval, opened and closed on THIS stream; the commit (decode stream, possibly several stages later) is timed
+    // as "prefill_commit"
+    if (int rc = prefill_layers(ctx, seq0, nseq, embeds, seq_len, (hipStream_t)stream, "aur_llm_prefill_stage")) return rc;
+    stage_end(ctx, "prefill", (hipStream_t)stream);
+    return AUR_OK;
 }
 
 // page-table rows of sequences [a0, a0 + n) <-> [b0, b0 + n)
@@ -940,6 +948,7 @@ extern "C" int aur_llm_prefill_commit(aur_ctx* ctx, int32_t slot0, int32_t nseq,
     if (seq0 != slot0 && seq0 < slot0 + nseq && slot0 < seq0 + nseq) return aur_fail(ctx, AUR_ERR_ARG, "aur_llm_prefill_commit: slot and sequence ranges overlap");
     if (seq_len < 1 || seq_len + ctx->max_new > ctx->cfg.max_ctx) return aur_fail(ctx, AUR_ERR_ARG, "seq_len %d + max_new %d exceeds max_ctx %d", seq_len, ctx->max_new, ctx->cfg.max_ctx);
     hipStream_t s = (hipStream_t)stream;
+    stage_begin(ctx, "prefill_commit", s);
     if (seq0 != slot0) {
         const int n = nseq * ctx->l_max_pages;
         hipLaunchKernelGGL(ptab_swap_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->ptab_rw(), slot0, seq0, nseq, ctx->l_max_pages);
@@ -949,7 +958,7 @@ extern "C" int aur_llm_prefill_commit(aur_ctx* ctx, int32_t slot0, int32_t nseq,
     CK(hipMemsetAsync(ctx->s_fin + slot0, 0, (size_t)nseq * 4, s));
     CK(hipMemsetAsync(ctx->s_pos + slot0, 0, (size_t)nseq * 4, s));
     CK(hipMemsetAsync(ctx->s_ids + (int64_t)slot0 * ctx->max_new, 0, (size_t)nseq * ctx->max_new * 4, s));
-    return prefill_first_tokens(ctx, slot0, nseq, embeds, seq_len, s);
+    return prefill_first_tokens(ctx, slot0, nseq, embeds, seq_len, s, "prefill_commit");
 }
 extern "C" int aur_llm_prefill(aur_ctx* ctx, int32_t slot, void* embeds, int32_t seq_len, void* stream) {
     return aur_llm_prefill_batch(ctx, slot, 1, embeds, seq_len, stream);
@@ -1125,13 +1134,19 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
     else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
-    else if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
-    else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
-    else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
-    else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = value ? 1 : 0;
-    else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
-
-    else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
+    else if (!strncmp(name, "gemm_", 5) || !strcmp(name, "microbench_prefill_nseq")) {
+        // GEMM knobs: no GEMM is part of the captured decode step (its projections are the skinny kernels), so the graphs stay
+        // valid - the serving schedule changes gemm_max_wgs around every front end (caption_stream) while decode launches are queued
+        if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
+        else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
+        else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
+        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = value ? 1 : 0;
+        else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
+        else if (!strcmp(name, "gemm_lab")) ctx->gemm_lab = (value >= 0 && value <= 7) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only
+        else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
+        else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
+        return AUR_OK;
+    }
     else if (!strcmp(name, "dec_attn_pps")) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
@@ -1142,7 +1157,10 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         ctx->decode_half = value ? 1 : 0;
         return AUR_OK;
     } else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
-    drop_graphs(ctx);             // kernel arguments are frozen in the captured graphs
+    // kernel arguments are frozen in the captured graphs.  A graph may still be queued on a stream this call does not know: wait
+    // for the device before destroying it (tuning path only - nothing in the serving schedules changes these knobs)
+    if (ctx->graph || ctx->graph_h) (void)hipDeviceSynchronize();
+    drop_graphs(ctx);
     return AUR_OK;
 }
 

@@ -23,6 +23,25 @@
 #include "gemm_epilogue.h"
 #include "tile_order.h"
 
+// ---- lab instantiations (tools/cumask/contention_lab.py; never launched by the product path: GemmArgs.lab == 0 there).
+// TAG >= GT_LAB_BASE selects a deliberately altered kernel that answers "what does the front-end GEMM take away from a concurrent
+// decode stream?": cache-policy bits on the operand DMAs, no DMA at all (power / clock only), no MFMA (fabric traffic only), or the
+// activation operand read from a K-tile-major image (DRAM-friendly 32 KiB blocks instead of 128-byte row pieces; results are garbage).
+template <int TAG> struct G2Lab {
+    static constexpr int id = TAG >= GT_LAB_BASE ? TAG - GT_LAB_BASE : 0;
+    static constexpr int aux_a = (id == 1 || id == 3) ? 2 : (id == 4 ? 16 : 0);     // 2 = nt, 16 = sc1
+    static constexpr int aux_w = (id == 2 || id == 3) ? 2 : (id == 4 ? 16 : 0);
+    static constexpr bool no_dma = id == 5;
+    static constexpr bool no_mfma = id == 6;
+    static constexpr bool a_tiled = id == 7;
+};
+template <int AUX>
+__device__ __forceinline__ void glds16x(const void* gsrc_lane, void* lds_wave_base) {
+    if constexpr (AUX == 0) __builtin_amdgcn_global_load_lds(GPTR(gsrc_lane), LPTR(lds_wave_base), 16, 0, 0);
+    else if constexpr (AUX == 2) __builtin_amdgcn_global_load_lds(GPTR(gsrc_lane), LPTR(lds_wave_base), 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds(GPTR(gsrc_lane), LPTR(lds_wave_base), 16, 0, 16);
+}
+
 #define G2_LDS (160 * 1024)
 #define G2_SLOT 16384
 #define G2_ABUF (2 * G2_SLOT)          // one activation buffer (2 half-tiles)
@@ -44,6 +63,7 @@ struct G2Src {
     const half_t* a[2][2];
     const half_t* w[2][2];
 };
+template <int TAG>
 __device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, int w, int lane, G2Src& src) {
     const int K32 = a.K >> 5;
     const int m0 = bm * 256;
@@ -56,44 +76,51 @@ __device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, in
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             int m = m0 + h * 128 + row;
             m = m < a.M ? m : a.M - 1;
-            src.a[h][i] = a.A + (int64_t)m * a.lda + c * 8;
+            if constexpr (G2Lab<TAG>::a_tiled) src.a[h][i] = a.A + ((int64_t)bm * (a.K >> 6) * 256 + h * 128 + row) * 64 + c * 8;
+            else src.a[h][i] = a.A + (int64_t)m * a.lda + c * 8;
             const int f = grp;                      // fragment of the half-tile: n16 = f >> 1, kk = f & 1
             src.w[h][i] = a.W + ((int64_t)(bn * 16 + h * 8 + (f >> 1)) * K32 + (f & 1)) * AUR_FRAG_HALVES + lane * 8;
         }
 }
+template <int TAG>
 __device__ __forceinline__ void g2_stage_a(const G2Src& src, char* smem, int w, int h, int kt) {
+    if constexpr (G2Lab<TAG>::no_dma) return;
     char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
-    glds16(src.a[h][0] + kt * 64, dst + (w * 2 + 0) * 1024);
-    glds16(src.a[h][1] + kt * 64, dst + (w * 2 + 1) * 1024);
+    const int64_t step = G2Lab<TAG>::a_tiled ? (int64_t)kt * 256 * 64 : (int64_t)kt * 64;
+    glds16x<G2Lab<TAG>::aux_a>(src.a[h][0] + step, dst + (w * 2 + 0) * 1024);
+    glds16x<G2Lab<TAG>::aux_a>(src.a[h][1] + step, dst + (w * 2 + 1) * 1024);
 }
+template <int TAG>
 __device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, int h, int kt, int wb) {       // wb = kt % 3
+    if constexpr (G2Lab<TAG>::no_dma) return;
     char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
-    glds16(src.w[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
-    glds16(src.w[h][1] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 1) * 1024);
+    glds16x<G2Lab<TAG>::aux_w>(src.w[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
+    glds16x<G2Lab<TAG>::aux_w>(src.w[h][1] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 1) * 1024);
 }
 // prologue of a tile: K-tile 0 completely (8 instructions), plus W0, W1, A0 of K-tile 1 (6 instructions that may stay in flight)
+template <int TAG>
 __device__ __forceinline__ void g2_prologue(const GemmArgs& a, const G2Src& src, char* smem, int w) {
-    g2_stage_a(src, smem, w, 0, 0);
-    g2_stage_a(src, smem, w, 1, 0);
-    g2_stage_w(src, smem, w, 0, 0, 0);
-    g2_stage_w(src, smem, w, 1, 0, 0);
+    g2_stage_a<TAG>(src, smem, w, 0, 0);
+    g2_stage_a<TAG>(src, smem, w, 1, 0);
+    g2_stage_w<TAG>(src, smem, w, 0, 0, 0);
+    g2_stage_w<TAG>(src, smem, w, 1, 0, 0);
     if ((a.K >> 6) > 1) {
-        g2_stage_w(src, smem, w, 0, 1, 1);
-        g2_stage_w(src, smem, w, 1, 1, 1);
-        g2_stage_a(src, smem, w, 0, 1);
+        g2_stage_w<TAG>(src, smem, w, 0, 1, 1);
+        g2_stage_w<TAG>(src, smem, w, 1, 1, 1);
+        g2_stage_a<TAG>(src, smem, w, 0, 1);
     }
 }
 
 // K loop of one tile.  On entry the tile's prologue has been ISSUED (g2_prologue); `first` = nothing else is in flight, so the
 // counted wait of the original prologue applies; otherwise the previous tile's epilogue stores are in flight behind the DMAs and
 // the wait drains everything (stores and loads share vmcnt).
-template <int EPI, bool VMODE>
+template <int EPI, bool VMODE, int TAG>
 __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src, char* smem, f4 (&acc)[4][8], int w, int lane, bool first) {
     const int wr = w >> 2, wc = w & 3;
     const int r = lane & 15, g = lane >> 4;
     const int nkt = a.K >> 6;
-    auto stage_a = [&](int h, int kt) { g2_stage_a(src, smem, w, h, kt); };
-    auto stage_w = [&](int h, int kt, int wb) { g2_stage_w(src, smem, w, h, kt, wb); };
+    auto stage_a = [&](int h, int kt) { g2_stage_a<TAG>(src, smem, w, h, kt); };
+    auto stage_w = [&](int h, int kt, int wb) { g2_stage_w<TAG>(src, smem, w, h, kt, wb); };
 
     // fragment read offsets inside a buffer
     const int sw = (r >> 1) & 7;
@@ -124,6 +151,8 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
+        if (G2Lab<TAG>::no_mfma) __builtin_amdgcn_s_sleep(4);      /* lab: the burst's duration without its power */ \
+        else                                                                                                 \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
             _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                  \
                 _Pragma("unroll") for (int uu = 0; uu < 4; ++uu) {                                            \
@@ -296,8 +325,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     int bm, bn;
     G2Src src;
     tile_of(blockIdx.x, bm, bn);
-    g2_sources(a, bm, bn, w, lane, src);
-    g2_prologue(a, src, smem, w);
+    g2_sources<TAG>(a, bm, bn, w, lane, src);
+    g2_prologue<TAG>(a, src, smem, w);
     bool first = true;
     for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
         f4 acc[4][8];
@@ -308,16 +337,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int nb = bn * 256 + (w & 3) * 64;
         const int mb = bm * 256 + (w >> 2) * 128;
         const bool vmode = (EPI == EPI_QKV) && (nb >= a.q_cols + a.k_cols);
-        if (vmode) g2_mainloop<EPI, true>(a, src, smem, acc, w, lane, first);
-        else g2_mainloop<EPI, false>(a, src, smem, acc, w, lane, first);
+        if (vmode) g2_mainloop<EPI, true, TAG>(a, src, smem, acc, w, lane, first);
+        else g2_mainloop<EPI, false, TAG>(a, src, smem, acc, w, lane, first);
         first = false;
         // every wave is past the K loop's last barrier: all LDS reads of this tile are done -> start the next tile's loads now,
         // they fly while this tile's epilogue converts and stores
         const int nxt = bid + gridDim.x;
         if (nxt < nwg) {
             tile_of(nxt, bm, bn);
-            g2_sources(a, bm, bn, w, lane, src);
-            g2_prologue(a, src, smem, w);
+            g2_sources<TAG>(a, bm, bn, w, lane, src);
+            g2_prologue<TAG>(a, src, smem, w);
         }
         // 16-byte row accesses need 8-column alignment of every row (ldc, ldr multiples of 8 halves; SiLU*up writes n / 2: ldc % 4)
         const bool wide = EPI == EPI_ROW && a.wide_epilogue && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
@@ -343,6 +372,11 @@ hipError_t gemm256_init() {
         (e = g2_attr<EPI_ROW, GT_LLM_DOWN>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_OTHER>()) != hipSuccess ||
         (e = g2_attr<EPI_QKV, GT_VIT_QKV>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_LLM_QKV>()) != hipSuccess)
         return e;
+    if ((e = g2_attr<EPI_ROW, GT_LAB_BASE + 1>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 2>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 3>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 4>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 5>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 6>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess)
+        return e;
     return hipSuccess;
 }
 
@@ -361,7 +395,18 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     if (ntiles > cap) ntiles = cap;
     dim3 grid(ntiles), block(512);
 #define G2_LAUNCH(E, T) hipLaunchKernelGGL((gemm256_kernel<E, T>), grid, block, G2_LDS, s, a)
-    if (epi == EPI_ROW) {
+    if (epi == EPI_ROW && a.lab > 0) {            // lab instantiations only (contention_lab.py)
+        switch (a.lab) {
+            case 1: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 1); break;
+            case 2: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 2); break;
+            case 3: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 3); break;
+            case 4: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 4); break;
+            case 5: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 5); break;
+            case 6: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 6); break;
+            case 7: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 7); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (epi == EPI_ROW) {
         switch (a.tag) {
             case GT_VIT_OUT: G2_LAUNCH(EPI_ROW, GT_VIT_OUT); break;
             case GT_VIT_FC1: G2_LAUNCH(EPI_ROW, GT_VIT_FC1); break;

@@ -34,11 +34,12 @@ struct GemmArgs {
     int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
     int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
     int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
+    int lab;                // 0 in the product path; > 0 = lab instantiation of the 256x256 kernel (gemm256.hip G2Lab, EPI_ROW only)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
                             // grid is the same for every shape) separate the shapes - profiles/*_kernel_stats.txt, *_pmc.json
 };
-enum { GT_OTHER = 0, GT_VIT_QKV, GT_VIT_OUT, GT_VIT_FC1, GT_VIT_FC2, GT_LLM_QKV, GT_LLM_O, GT_LLM_GATEUP, GT_LLM_DOWN, GT_COUNT };
+enum { GT_OTHER = 0, GT_VIT_QKV, GT_VIT_OUT, GT_VIT_FC1, GT_VIT_FC2, GT_LLM_QKV, GT_LLM_O, GT_LLM_GATEUP, GT_LLM_DOWN, GT_COUNT, GT_LAB_BASE = 32 };
 
 hipError_t gemm_init();
 hipError_t attn_init();

@@ -211,6 +211,13 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const float* __restrict
             }
             // agent-scope stores / loads for the hand-over below: the frame's workgroups sit on different XCDs, whose L2s are not
             // coherent for plain accesses.  (Full release / acquire fences - an L2 write-back per workgroup - cost ~100 us per launch.)
+            // This is the guide's "sc1 payload -> drained vmcnt -> sc1 flag, sc1 loads on the consumer" form (MI355X_MICROARCH.md,
+            // valid forms / handoff-flag row): relaxed agent-scope atomics lower to write-through `sc1` stores and L1-bypassing
+            // `sc1` loads on gfx950, and the hand-written s_waitcnt below orders payload before arrival.  It is NOT a HIP-memory-model
+            // release / acquire pair - hence the architecture guard; tests/test_gpu_kernels.py stresses it under uneven load.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "tome_match_kernel's hand-over relies on gfx950 sc1 write-through semantics; use release/acquire fences on other targets"
+#endif
             __hip_atomic_store(node_max + (int64_t)f * ta + i, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(node_idx + (int64_t)f * ta + i, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -615,7 +615,11 @@ class AuroraCapEngine:
                         self.decode(check_every - k1)
                 # 3. prepare the next clips into every free spare sequence (front-end stream: runs beside the decode above)
                 while free_seqs and not exhausted:
-                    nxt = next(it, None)
+                    # the iterator may be lazy (the lmms-eval adaptor decodes and preprocesses a clip when asked): whatever it
+                    # enqueues on torch's current stream must be ordered before the front end that reads it -> pull the clip
+                    # with the front-end stream current, so its kernels and allocations belong to that stream
+                    with torch.cuda.stream(sF):
+                        nxt = next(it, None)
                     if nxt is None:
                         exhausted = True
                         break
@@ -623,6 +627,8 @@ class AuroraCapEngine:
                     seq = free_seqs.pop()
                     try:
                         with torch.cuda.stream(sF):
+                            if torch.is_tensor(px) and px.is_cuda:
+                                px.record_stream(sF)              # allocated on another stream (a prebuilt clip): not reusable before sF is done with it
                             if seq in reusable:
                                 sF.wait_event(reusable.pop(seq))
                             r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])

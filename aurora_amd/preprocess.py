@@ -56,7 +56,7 @@ def read_video_pyav(path: str, num_frm: int = 8):
     try:                                                           # load_video.py:35-47: "for mp4, we try loading with stream first"
         container = av.open(path)
         total = container.streams.video[0].frames
-        if total <= 0:
+        if total <= 0:                                             # no frame count in the header: the reference raises (np.stack of nothing); deliberate fall-back
             return by_packets()
         idx = sample_frame_indices(total, num_frm)
         want, out = set(idx), {}
@@ -65,9 +65,12 @@ def read_video_pyav(path: str, num_frm: int = 8):
                 out[i] = frame.to_ndarray(format="rgb24")
             if i >= idx[-1]:
                 break
-        if len(out) != len(idx):                                   # the header promised more frames than the stream holds
+        # a header that promised more frames than the stream holds: the reference returns the (shorter) list of frames it found
+        # (record_video_length_stream, load_video.py:7-16, 46) - no re-sampling.  Only when NOTHING was found, where the reference
+        # dies in np.stack([]), do we decode by packets instead (deliberate: a caption beats a ValueError)
+        if not out:
             return by_packets()
-        return np.stack([out[i] for i in idx])
+        return np.stack([out[i] for i in idx if i in out])
     except Exception:                                              # noqa: BLE001 - the reference catches everything here too
         return by_packets()
 

@@ -219,3 +219,53 @@ def test_caption_stream_with_front_ends_prefetched_beside_the_decode():
             list(build(2).caption_stream(cs[:2], 0.5, 7, overlap=True))          # no spare sequences
     finally:
         eng.close()
+
+
+def test_overlapped_stream_with_a_lazy_clip_source_on_the_current_stream():
+    """the lmms-eval adaptor hands caption_stream a LAZY iterable - a clip is decoded and preprocessed
+    (`FramePreprocessor`, torch's current stream) only when the stream asks for it.  In the overlapped schedule that pull must
+    happen with the front-end stream current, or the ViT reads pixel_values the decode stream has not produced yet.  Large input
+    frames (a slow input stage) behind a busy decode stream make the unordered version fail; every clip must equal itself alone."""
+    from aurora_amd.engine import AuroraCapEngine
+    from aurora_amd.lmms_plugin.models import auroracap_mi355x as P
+    from aurora_amd.model import AuroraModel
+    from aurora_amd.preprocess import FramePreprocessor
+    from tests.test_lmms_plugin import FakeTok
+    eng = AuroraCapEngine({"vit": VCFG, "llm": LLM_CFGS["hd32"]}, weights(), max_frames=4, max_batch=4, max_ctx=512,
+                          max_new_tokens=24, spare_slots=2)
+    try:
+        pre = FramePreprocessor(image=56)
+        rng = np.random.default_rng(5)
+        raw = [rng.integers(0, 256, (1 + i % 4, 1080, 1920, 3), dtype=np.uint8) for i in range(10)]      # 1080p: a real input stage
+        prompts = [[1, 17 + i % 2] + [-200, 30] * len(raw[i]) + [40] for i in range(10)]
+        want = []
+        for i in range(10):
+            px = pre(torch.from_numpy(raw[i]).cuda())
+            want.append(eng.caption_ids(px, prompts[i], 0.5, 24, eos_id=None))
+        torch.cuda.synchronize()
+
+        def lazy():
+            for i in range(10):
+                yield pre(torch.from_numpy(raw[i]).cuda(non_blocking=True)), prompts[i]       # enqueued on whatever stream is current
+
+        for rep in range(3):
+            got = dict(eng.caption_stream(lazy(), 0.5, 24, eos_id=None, check_every=4))
+            assert sorted(got) == list(range(10))
+            for i in range(10):
+                assert got[i] == want[i], (rep, i)
+        # the adaptor's own default path: batch_size > 1 on an engine with spare sequences = overlapped, clips built lazily by _clip
+        m = AuroraModel(eng, eos_token_id=None)
+        ad = P.AuroraCapMI355X(pretrained="unused", device="cuda", batch_size=4, token_merge_ratio=0.5, _model=m, _tokenizer=FakeTok(),
+                               _preprocessor=pre)
+        docs = {i: raw[i] for i in range(10)}
+        ad.task_dict = {"vdc": {"test": docs}}
+        ctxs = ["describe " + "y" * i for i in range(10)]
+        reqs = [SimpleNamespace(args=(ctxs[i], {"max_new_tokens": 8}, lambda d: [d], i, "vdc", "test")) for i in range(10)]
+        texts = ad.generate_until(reqs)
+        tok = FakeTok()
+        for i in range(10):
+            px = pre(torch.from_numpy(raw[i]).cuda())
+            ids = P.tokenizer_image_token(P.conv_prompt(P.question_with_image_tokens(ctxs[i], len(raw[i]))), tok)
+            assert texts[i] == " ".join(map(str, eng.caption_ids(px, ids, 0.5, 8, eos_id=None))), i
+    finally:
+        eng.close()

@@ -1,0 +1,54 @@
+// clock_probe - effective shader clock while other kernels run (lab tool, not part of the product)
+//   hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/cumask/clock_probe.hip -o tools/cumask/libclock_probe.so
+// One wave spins for `spin_us` of the constant 100 MHz counter (s_memrealtime) and reports how many shader cycles (s_memtime) went by:
+// MHz = 100 * cycles / ticks.  Launch it into an unmasked stream next to the kernels under study.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__global__ void clock_probe_kernel(uint64_t* out, uint64_t ticks) {
+    const uint64_t w0 = wall_clock64();
+    const uint64_t c0 = clock64();
+    uint64_t w1 = w0;
+    while (w1 - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        w1 = wall_clock64();
+    }
+    const uint64_t c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+}
+
+// out_dev: 2 x uint64 of device memory; returns the hipError_t of the launch
+extern "C" int clock_probe_launch(void* stream, uint64_t* out_dev, int spin_us) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev, (uint64_t)spin_us * 100);
+    return (int)hipGetLastError();
+}
+
+// ---- a read streamer for the contention lab: every workgroup sweeps its share of [p, p + n16 * 16) `reps` times with 16-byte
+// loads (nt = 1: non-temporal).  A buffer of a few tens of MiB is served by the 256 MiB memory-side cache after the first sweep
+// (never by a 4 MiB L2), a multi-GiB one by HBM: the same fabric traffic with and without HBM behind it.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void lab_stream_kernel(const f4v* __restrict__ p, int64_t n16, int reps, float* sink) {
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < reps; ++r)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256 * 4) {
+            f4v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = i + (int64_t)u * gridDim.x * 256;
+                if (j < n16) v[u] = NT ? __builtin_nontemporal_load(p + j) : p[j];
+                else v[u] = f4v{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+    if (acc.x == 1.2345f) sink[0] = acc.y + acc.z + acc.w;
+}
+extern "C" int lab_stream_launch(void* stream, const void* p, int64_t bytes, int reps, int blocks, int nt, float* sink) {
+    if (nt) hipLaunchKernelGGL(lab_stream_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f4v*)p, bytes / 16, reps, sink);
+    else hipLaunchKernelGGL(lab_stream_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f4v*)p, bytes / 16, reps, sink);
+    return (int)hipGetLastError();
+}
