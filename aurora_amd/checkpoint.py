@@ -19,19 +19,30 @@ import torch
 
 
 def _load_state(d: str) -> Dict[str, torch.Tensor]:
+    """All tensors of one `save_pretrained` directory: safetensors or torch-pickle files, single or sharded.  A shard index
+    (`*.index.json`, written next to sharded weights) is authoritative: exactly the files its weight_map names are read and
+    every key it lists must turn up - a directory holding stale extra weight files is then still read correctly."""
     sd: Dict[str, torch.Tensor] = {}
-    st = sorted(glob.glob(os.path.join(d, "*.safetensors")))
-    if st:
-        from safetensors.torch import load_file
-        for f in st:
-            sd.update(load_file(f))
+    for pattern, idx_name in (("*.safetensors", "model.safetensors.index.json"), ("pytorch_model*.bin", "pytorch_model.bin.index.json")):
+        files = sorted(glob.glob(os.path.join(d, pattern)))
+        idx = os.path.join(d, idx_name)
+        wmap = _json(idx)["weight_map"] if os.path.exists(idx) else None
+        if wmap is not None:
+            files = [os.path.join(d, f) for f in sorted(set(wmap.values()))]
+        if not files:
+            continue
+        for f in files:
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd.update(load_file(f))
+            else:
+                sd.update(torch.load(f, map_location="cpu", weights_only=True))
+        if wmap is not None:
+            missing = [k for k in wmap if k not in sd]
+            if missing:
+                raise KeyError(f"{idx_name} lists tensors its shards do not hold: {missing[:4]}")
         return sd
-    bins = sorted(glob.glob(os.path.join(d, "pytorch_model*.bin")))
-    if not bins:
-        raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {d}")
-    for f in bins:
-        sd.update(torch.load(f, map_location="cpu", weights_only=True))
-    return sd
+    raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {d}")
 
 
 def _json(p):
@@ -52,13 +63,19 @@ def llm_config(d: str) -> dict:
     c = _json(os.path.join(d, "config.json"))
     if c.get("num_key_value_heads", c["num_attention_heads"]) != c["num_attention_heads"]:
         raise NotImplementedError("grouped-query attention is not on the AuroraCap-7B path (vicuna-7b is MHA)")
-    rs = c.get("rope_scaling") or {}
+    # transformers <= 4.x (the reference's pin; vicuna-7b-v1.5-16k): "rope_scaling": {"type": "linear", "factor": 4.0} + "rope_theta";
+    # transformers 5.x writes ONE dict instead: "rope_parameters": {"rope_type": "linear", "factor": 4.0, "rope_theta": ...}
+    rp = c.get("rope_parameters") or {}
+    rs = c.get("rope_scaling") or {k: v for k, v in rp.items() if k != "rope_theta"}
+    if set(rs) <= {"rope_type", "type"} and rs.get("rope_type", rs.get("type")) in (None, "default"):
+        rs = {}
     kind = rs.get("type", rs.get("rope_type", "linear" if rs else None))
     if rs and kind not in ("linear", "default", None):
         raise NotImplementedError(f"rope_scaling type {kind!r} (vicuna-7b-v1.5-16k uses linear)")
+    theta = c.get("rope_theta", rp.get("rope_theta", 10000.0))
     return dict(hidden_size=c["hidden_size"], num_attention_heads=c["num_attention_heads"],
                 num_hidden_layers=c["num_hidden_layers"], intermediate_size=c["intermediate_size"],
-                vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-5), rope_theta=c.get("rope_theta", 10000.0),
+                vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-5), rope_theta=theta,
                 rope_factor=float(rs.get("factor", 1.0)) if kind == "linear" else 1.0,
                 eos_token_id=c.get("eos_token_id", 2), bos_token_id=c.get("bos_token_id", 1))
 
@@ -69,7 +86,9 @@ def vit_weights(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
         p = ""
     g = lambda k: sd[p + k]
     w = {"patch_embedding.weight": g("embeddings.patch_embedding.weight"), "class_embedding": g("embeddings.class_embedding"),
-         "position_embedding.weight": sd.get("pos_emb", g("embeddings.position_embedding.weight")),
+         # the table the reference's forward really uses is its `pos_emb` alias (aurora.py:878, 899); a checkpoint saved through
+         # safetensors cannot hold both names of one tensor and keeps either - take whichever is there
+         "position_embedding.weight": sd["pos_emb"] if "pos_emb" in sd else g("embeddings.position_embedding.weight"),
          "pre_layrnorm.weight": g("pre_layrnorm.weight"), "pre_layrnorm.bias": g("pre_layrnorm.bias"), "layers": []}
     for i in range(cfg["num_hidden_layers"]):
         q = f"encoder.layers.{i}."
@@ -98,9 +117,10 @@ def llm_weights(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
     return w
 
 
-def load_auroracap(root: str) -> Tuple[dict, dict]:
-    """(cfg, weights) from an xtuner-format AuroraCap directory."""
-    vdir, pdir = os.path.join(root, "visual_encoder"), os.path.join(root, "projector")
+def load_auroracap(root: str, visual_encoder: str = "visual_encoder", projector: str = "projector") -> Tuple[dict, dict]:
+    """(cfg, weights) from an xtuner-format AuroraCap directory (inference.py:42-45: <root>, <root>/visual_encoder,
+    <root>/projector; the sub-directory names can be overridden)."""
+    vdir, pdir = os.path.join(root, visual_encoder), os.path.join(root, projector)
     for d in (root, vdir, pdir):
         if not os.path.isdir(d):
             raise FileNotFoundError(f"{d} is not a directory (expected <root>/, <root>/visual_encoder, <root>/projector)")

@@ -61,14 +61,19 @@ def main():
         if not osp.isdir(args.model_path):
             from huggingface_hub import snapshot_download
             args.model_path = snapshot_download(repo_id=args.model_path)
+        # input size / patch size come from the checkpoint's own config; the reference writes the AuroraCap-7B values
+        # (size=378, crop_size=378, inference.py:58-63) into its processor call, which is what the release's config says too
+        from aurora_amd.checkpoint import vit_config
+        vcfg = vit_config(osp.join(args.model_path, "visual_encoder"))
+        image_size, patch = vcfg["image_size"], vcfg["patch_size"]
         if args.host_preprocess:      # the reference's host path (PIL); default is the bit-identical HIP input stage
-            image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=378, crop_size=378)
+            image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=image_size, crop_size=image_size)
 
             def to_pixels(frames):
                 return image_processor(list(frames), return_tensors='pt')['pixel_values'].to(dtype=torch.float16)
         else:
             from aurora_amd.preprocess import FramePreprocessor
-            gpu_pre = FramePreprocessor(image=378)
+            gpu_pre = FramePreprocessor(image=image_size)
 
             def to_pixels(frames):
                 return gpu_pre(torch.from_numpy(np.ascontiguousarray(np.stack(list(frames)))).cuda())
@@ -89,7 +94,7 @@ def main():
         # The engine's capacity comes from THIS request: read_video_pyav may return num_frm + 1 frames and the
         # prompt length is only known after tokenising, so size the context from the spliced length, not from the flags.
         n_text = int((data["input_ids"] != -200).sum())
-        per_frame = (378 // 14) ** 2                                      # upper bound: token_kept_ratio = 1.0 keeps all patches
+        per_frame = (image_size // patch) ** 2                                      # upper bound: token_kept_ratio = 1.0 keeps all patches
         max_ctx = -(-(n_text + n_img * per_frame + args.max_new_tokens) // 64) * 64
         model = AuroraModel.from_pretrained(args.model_path, max_frames=max(n_img, 1), max_ctx=max_ctx,
                                             max_new_tokens=args.max_new_tokens)

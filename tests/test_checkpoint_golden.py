@@ -1,0 +1,84 @@
+"""CPU: the checkpoint loader against a directory this repo did NOT write (tests/golden/ckpt_tiny, made by
+tests/golden/make_golden_checkpoint.py in the build container): HF `LlamaForCausalLM.save_pretrained` shards + index + config,
+the reference's `ProjectorModel.save_pretrained`, the CLIP tower in the layout of the reference's pin (`vision_model.*` keys + the
+`pos_emb` alias, torch pickle) and in transformers 5's own (flat keys, safetensors).  `load_auroracap` must turn each into the
+oracle's weights such that the ORACLE reproduces what the HF / reference-side stack computed from the same directory
+(g13_checkpoint_e2e.npz): ViT + ToMe features, spliced embeddings, greedy ids and logits - inference.py:42-57, aurora.py:214-258."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aurora_amd import checkpoint as CK
+from oracle import aurora_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "golden", "ckpt_tiny")
+G13 = os.path.join(HERE, "golden", "g13_checkpoint_e2e.npz")
+
+
+@pytest.mark.parametrize("visual", ["visual_encoder", "visual_encoder_hf5"])
+def test_loader_and_oracle_reproduce_the_reference_side_stack(visual):
+    g = np.load(G13)
+    cfg, w = CK.load_auroracap(ROOT, visual_encoder=visual)
+    assert cfg["llm"]["rope_factor"] == 4.0 and cfg["llm"]["rope_theta"] == 10000.0 and cfg["llm"]["eos_token_id"] == 2
+    assert cfg["llm"]["hidden_size"] == 128 and cfg["llm"]["num_hidden_layers"] == 2 and cfg["llm"]["vocab_size"] == 320
+    assert cfg["vit"]["hidden_size"] == 64 and cfg["vit"]["patch_size"] == 14 and cfg["vit"]["image_size"] == 56
+    assert cfg["vit"]["hidden_act"] == "quick_gelu"
+    f32 = lambda t: {k: ([f32(x) for x in v] if isinstance(v, list) else v.float()) for k, v in t.items()}
+    w = {k: f32(v) for k, v in w.items()}                                  # fp16 on disk, fp32 arithmetic (as the generator ran it)
+    px = torch.from_numpy(g["pixel_values"]).float()
+    ids = g["input_ids"][0].tolist()
+    ratio = float(g["ratio"])
+    feats = O.vit_features(px, w["vit"], cfg["vit"], ratio, None)
+    assert feats.shape[1] == int(g["n_kept"])
+    ref = torch.from_numpy(g["vis_feats"])
+    assert (feats - ref).norm() / ref.norm() < 1e-4                       # same merges, fp32 both sides
+    out, logits = O.caption_ids(px, ids, w, cfg, ratio, len(g["ids"]), eos_id=None, q=None, return_logits=True)
+    assert out == g["ids"].tolist()
+    rl = torch.from_numpy(g["logits"])
+    assert (logits - rl).abs().max() <= 2e-3 * rl.abs().max()
+
+
+def test_rope_config_spellings():
+    """transformers <= 4.x (the reference's pin, vicuna-7b-v1.5-16k) and 5.x spell linear rope scaling differently."""
+    base = dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=256, vocab_size=320)
+
+    def parse(extra, tmp):
+        with open(os.path.join(tmp, "config.json"), "w") as f:
+            json.dump(dict(base, **extra), f)
+        return CK.llm_config(tmp)
+
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        c = parse({"rope_scaling": {"factor": 4.0, "type": "linear"}, "rms_norm_eps": 1e-5}, tmp)          # 4.x style
+        assert c["rope_factor"] == 4.0 and c["rope_theta"] == 10000.0
+        c = parse({"rope_scaling": {"factor": 8.0, "rope_type": "linear"}, "rope_theta": 5e5}, tmp)
+        assert c["rope_factor"] == 8.0 and c["rope_theta"] == 5e5
+        c = parse({"rope_parameters": {"factor": 4.0, "rope_theta": 1e4, "rope_type": "linear", "type": "linear"}}, tmp)     # 5.x style
+        assert c["rope_factor"] == 4.0 and c["rope_theta"] == 1e4
+        c = parse({"rope_parameters": {"rope_theta": 1e6, "rope_type": "default"}}, tmp)
+        assert c["rope_factor"] == 1.0 and c["rope_theta"] == 1e6
+        c = parse({"rope_scaling": None}, tmp)
+        assert c["rope_factor"] == 1.0
+        with pytest.raises(NotImplementedError):
+            parse({"rope_scaling": {"type": "dynamic", "factor": 2.0}}, tmp)
+        with pytest.raises(NotImplementedError):
+            parse({"num_key_value_heads": 2}, tmp)
+
+
+def test_shard_index_is_authoritative(tmp_path):
+    """A stale consolidated file next to the shards must not be read; a shard the index names must exist."""
+    import shutil
+    d = tmp_path / "llm"
+    shutil.copytree(ROOT, d, ignore=shutil.ignore_patterns("visual_encoder*", "projector"))
+    good = CK._load_state(str(d))
+    from safetensors.torch import save_file
+    save_file({"model.norm.weight": torch.zeros(128, dtype=torch.float16)}, str(d / "zzz_stale.safetensors"))
+    again = CK._load_state(str(d))
+    assert set(again) == set(good) and torch.equal(again["model.norm.weight"], good["model.norm.weight"])
+    os.remove(d / "model-00002-of-00003.safetensors")
+    with pytest.raises(Exception):
+        CK._load_state(str(d))

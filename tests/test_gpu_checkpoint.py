@@ -96,3 +96,40 @@ def test_real_size_xtuner_checkpoint_through_from_pretrained(tmp_path):
         assert got == want, (got, want)
     finally:
         m.engine.close()
+
+
+@pytest.mark.parametrize("visual", ["visual_encoder", "visual_encoder_hf5"])
+def test_fixture_not_written_by_this_repo_through_from_pretrained(visual, tmp_path):
+    """tests/golden/ckpt_tiny: HF `save_pretrained` shards + index, the reference's own `ProjectorModel.save_pretrained`, the CLIP
+    tower in the pinned (`vision_model.*` + `pos_emb`, torch pickle) and the transformers-5 (flat, safetensors) layout; expected ids
+    and logits computed from that directory by HF / reference modules only (tests/golden/make_golden_checkpoint.py, G13).
+    `AuroraModel.from_pretrained` -> the three reference calls (inference.py:87-96) -> ids equal under the margin rule, with
+    positions really compared."""
+    import numpy as np
+    from aurora_amd.model import AuroraModel
+    from tests.test_gpu_llm import assert_greedy_agrees_up_to_margin
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "golden", "ckpt_tiny")
+    g = np.load(os.path.join(here, "golden", "g13_checkpoint_e2e.npz"))
+    root = str(tmp_path / "ckpt")                                    # the loader's fixed sub-directory names, via links
+    os.makedirs(root)
+    for f in os.listdir(src):
+        if not f.startswith("visual_encoder"):
+            os.symlink(os.path.join(src, f), os.path.join(root, f))
+    os.symlink(os.path.join(src, visual), os.path.join(root, "visual_encoder"))
+    N = len(g["ids"])
+    m = AuroraModel.from_pretrained(root, max_frames=4, max_batch=1, max_ctx=256, max_new_tokens=N)
+    try:
+        assert m.engine.l["rope_factor"] == 4.0 and m.engine.v["image_size"] == 56 and m.llm.eos_token_id == 2
+        m.visual_encoder.reset_tome_r(float(g["ratio"]))
+        px = torch.from_numpy(g["pixel_values"]).cuda()
+        out = m({"pixel_values": px.unsqueeze(0), "input_ids": torch.from_numpy(g["input_ids"])}, mode="inference")
+        emb = out["inputs_embeds"][0].float().cpu()
+        ref_emb = torch.from_numpy(g["embeds"])
+        assert emb.shape == ref_emb.shape
+        assert (emb - ref_emb).norm() / ref_emb.norm() < 2e-2          # ViT + ToMe + projector + splice in fp16 vs the fp32 stack
+        got = m.llm.generate(**out, do_sample=False, num_beams=1, max_new_tokens=N, eos_token_id=None)[0].tolist()
+        checked = assert_greedy_agrees_up_to_margin(got, g["ids"].tolist(), torch.from_numpy(g["logits"]), 1e-2)
+        assert checked >= 8, (checked, got, g["ids"].tolist())
+    finally:
+        m.engine.close()

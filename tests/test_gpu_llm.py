@@ -148,7 +148,7 @@ def test_projector_splice_and_whole_path():
          "llm": rand_llm_weights(lcfg, 3)}
     eng = AuroraCapEngine({"vit": vcfg, "llm": lcfg}, w, max_frames=3, max_batch=1, max_ctx=256, max_new_tokens=16)
     try:
-        gen = torch.Generator().manual_seed(12)
+        gen = torch.Generator().manual_seed(76)     # CPU search over the oracle alone: every one of the 12 steps has a clear margin at 1e-2
         px = torch.randn(3, 3, 56, 56, generator=gen).half().float()
         ids = [1, 17, -200, 18, -200, 19, -200, 20, 21, 22]
         # projector + splice alone (teacher-forced on the GPU's ViT features)
@@ -169,7 +169,10 @@ def test_projector_splice_and_whole_path():
         out = eng.caption_ids(px, ids, 0.5, 12, eos_id=None)
         assert len(out) == 12
         ref, ref_logits = O.caption_ids(px, ids, w, {"vit": vcfg, "llm": lcfg}, 0.5, 12, eos_id=None, q=O.fp16_storage, return_logits=True)
-        assert_greedy_agrees_up_to_margin(out, ref, ref_logits)
+        # tolerance 1e-2 of the logit scale (tiny-model drift is well below the kernel-level 3e-2; at 3e-2 a random tiny model leaves
+        # no position to compare) and the count is asserted: the check cannot pass vacuously
+        checked = assert_greedy_agrees_up_to_margin(out, ref, ref_logits, 1e-2)
+        assert checked >= 8, (checked, out, ref)
     finally:
         eng.close()
 
