@@ -34,6 +34,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# BASELINE.json `configs` by name.  cfg2 is the metric's workload (the default); cfg3 / cfg5 are its merge-dominated and long-KV
+# single-GPU cases (KV slots sized so that the pool fits 288 GB: 52 resp. 109 pages of 32 MiB per slot); cfg4 is cfg2 at 8 clips per GPU:
+# `--gpus 8 --config cfg4` is literally "batch of 64 clips sharded 8-way".  configs[0] is the reference's CPU-runnable case: it is
+# timed on the CPU oracle (`cpu_baseline.configs0`), on the GPU it is `--num_frm 1 --token_kept_ratio 1.0 --max_new_tokens 32 --batch 1`.
+CONFIGS = {
+    "cfg2": dict(what="configs[1]: 8 frames, ratio 0.3, 256 tokens, 128 slots per GPU", index=1,
+                 set=dict(num_frm=8, token_kept_ratio=0.3, max_new_tokens=256, batch=128)),
+    "cfg3": dict(what="configs[2]: 16 frames, ratio 0.2, 512 tokens (merge-dominated), 96 slots", index=2,
+                 set=dict(num_frm=16, token_kept_ratio=0.2, max_new_tokens=512, batch=96)),
+    "cfg4": dict(what="configs[3]: cfg2 at 8 clips per GPU - with --gpus 8 the batch of 64 clips sharded 8-way", index=3,
+                 set=dict(num_frm=8, token_kept_ratio=0.3, max_new_tokens=256, batch=8)),
+    "cfg5": dict(what="configs[4]: 8 frames, ratio 0.8 (OCR regime), 2048 tokens, long-KV hipGraph decode, 48 slots", index=4,
+                 set=dict(num_frm=8, token_kept_ratio=0.8, max_new_tokens=2048, batch=48)),
+}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -89,7 +105,17 @@ def parse():
                         "continuous batching (same work per step, first tokens ~5x later)")
     p.add_argument("--no-latency-point", action="store_true", help="(kept for old command lines; the continuous mode is the default now)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
-    return p.parse_args()
+    p.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                   help="a BASELINE.json config by name (sets --num_frm / --token_kept_ratio / --max_new_tokens / --batch; flags given "
+                        "explicitly on the command line still win): " + "; ".join(f"{k} = {v['what']}" for k, v in sorted(CONFIGS.items())))
+    args = p.parse_args()
+    args.config_name = args.config or "cfg2"
+    if args.config:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+        for k, val in CONFIGS[args.config]["set"].items():
+            if "--" + k not in given and "--" + k.replace("_", "-") not in given:
+                setattr(args, k, val)
+    return args
 
 
 def cpu_baseline(cfg, args, n_kept):
@@ -278,6 +304,7 @@ def main():
     plans = [eng.splice_plan(ids[b], F, n_kept) for b in range(B)]   # static per prompt: uploaded once, outside the loop
     torch.cuda.synchronize()
     ttft_ms = []
+    host_ttft = []
 
     def front(bank, record_ttft=False):
         """ViT + projector/splice + prefill of one batch into generation bank `bank` (enqueue only)."""
@@ -425,7 +452,32 @@ def main():
                 eng.set_option("gemm_max_wgs", 8 * fc)
             pending = [None]
 
+            # host-observed TTFT ("submit -> first generated token id on host"): the host clock from the moment a group's
+            # front end is submitted to the moment its first token ids have landed in pinned host memory.  A side stream waits for the
+            # commit, copies the group's ids (aur_slot_collect, device to device) and their first column to the host; a helper thread
+            # waits for that copy and stamps the clock, so the enqueueing thread never blocks.
+            import queue
+            import threading
+            sC = torch.cuda.Stream()
+            first_dev = torch.zeros(NG, G, N, dtype=torch.int32, device=dev)
+            first_len = torch.zeros(NG, G, dtype=torch.int32, device=dev)
+            first_host = torch.zeros(NG, G, dtype=torch.int32).pin_memory()
+            host_q = queue.Queue()
+
+            def poller():
+                while True:
+                    item = host_q.get()
+                    if item is None:
+                        return
+                    t_submit, ev = item
+                    ev.synchronize()
+                    host_ttft.append(1e3 * (time.perf_counter() - t_submit))
+
+            poll_thread = threading.Thread(target=poller, daemon=True)
+            poll_thread.start()
+
             def front_async(g):
+                t_host = time.perf_counter()
                 with torch.cuda.stream(sF):
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(sF)
@@ -435,18 +487,25 @@ def main():
                     eng.prefill_stage(B, G, emb_all, L0)
                     evf = torch.cuda.Event()
                     evf.record(sF)
-                return e0, evf
+                return e0, evf, t_host
 
             def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
                 for g in range(NG):
                     eng.slot_collect(g * G, G, ids_out[g], len_out[g])
-                    e0, evf = pending[0]
+                    e0, evf, t_host = pending[0]
                     sD.wait_event(evf)
                     eng.prefill_commit(g * G, G, B, emb_all, L0)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(sD)
                     if timed:
                         lat_ev.append((e0, e1))
+                        with torch.cuda.stream(sC):
+                            sC.wait_event(e1)
+                            eng.slot_collect(g * G, G, first_dev[g], first_len[g])
+                            first_host[g].copy_(first_dev[g, :, 0], non_blocking=True)
+                            e2 = torch.cuda.Event()
+                            e2.record(sC)
+                        host_q.put((t_host, e2))
                     # the chunk's decode is enqueued BEFORE the next front end (a few hundred launches on the host): both wait for
                     # the commit only, and the decode must never sit behind the host's enqueue time
                     n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
@@ -489,6 +548,11 @@ def main():
         if overlap and args.gemm_cus <= 0:
             eng.set_option("gemm_max_wgs", 0)                      # the instrumented pass below runs alone on the whole GPU
         ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
+        if overlap:
+            host_q.put(None)
+            poll_thread.join()
+            # the copied first ids are the captions' first ids (the read-back is real, not a timestamp of nothing)
+            assert all(int(first_host[g, j]) == batch_ref[g * G + j][0] for g in range(NG) for j in range(G)), "host read-back of the first tokens disagrees"
     elif not pipe:
         for _ in range(args.warmup):
             step()
@@ -556,23 +620,39 @@ def main():
             ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
         eng.select_bank(0)
     assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
+    per_rank_ms, gather_us = None, None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock around the same K steps (the line's time is their MAX), so that a slow rank or a slow link shows in
+        # the record itself; and the cost of the one collective of the path, timed on its own after the steps
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        allt = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [1e3 * float(t.item()) / args.steps for t in allt]
+        elapsed = max(float(t.item()) for t in allt)
+        fence()
+        t_g = time.perf_counter()
+        for _ in range(5):
+            parallel.gather_results(out, N, B, cdev)
+        if cdev != "cpu":
+            torch.cuda.synchronize()
+        gather_us = 1e6 * (time.perf_counter() - t_g) / 5
 
     result = None
     if rank == 0:
         captions = world * B * args.steps
         value = captions / elapsed
         result = {
-            "metric": "captions/sec (AuroraCap-7B, 8-frame clips, token_kept_ratio 0.3, 256 new tokens) + p50 TTFT",
+            "metric": "captions/sec (AuroraCap-7B, %d-frame clips, token_kept_ratio %g, %d new tokens) + p50 TTFT" % (F, args.token_kept_ratio, N),
             "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "rccl_ranks": world if (world > 1 and backend == "nccl") else (0 if world > 1 else 1), "dist_backend": backend if world > 1 else "none",
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_per_rank": per_rank_ms, "ids_all_gather_us": gather_us,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[1])"
-                                    % (F, args.token_kept_ratio, N)) if not args.tiny else "tiny plumbing config (NOT the metric)",
+            "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[%d]%s)"
+                                    % (F, args.token_kept_ratio, N, CONFIGS[args.config_name]["index"],
+                                       "" if (F, args.token_kept_ratio, N) == tuple(CONFIGS[args.config_name]["set"][k] for k in ("num_frm", "token_kept_ratio", "max_new_tokens"))
+                                       else " with overridden flags")) if not args.tiny else "tiny plumbing config (NOT the metric)",
+                       "preset": args.config_name,
                        "clips_per_gpu_per_step": B, "frames": F, "token_kept_ratio": args.token_kept_ratio, "r_per_layer": r,
                        "visual_tokens_per_clip": F * n_kept, "prefill_len": L0, "max_new_tokens": N, "parallelism": f"clip-parallel x{world}",
                        "decode": "hipGraph" if not args.no_graph else "eager", "prefill_group": G, "vit_chunk": G if continuous else VC,
@@ -584,6 +664,10 @@ def main():
                                    % (fc, k_masked, 32 - fc) if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
+            "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
+            "ttft_host_note": ("host clock from the submission of a group's front end to its first token ids sitting in pinned host memory (a side "
+                               "stream copies them after the commit; a helper thread waits for the copy), same cycles as the timed region"
+                               if (continuous and overlap) else None),
             "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "
                            "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1)
                            + ("; the front end runs on the front-end stream during the chunk before the group's boundary and its first tokens "
@@ -712,6 +796,18 @@ def main():
             torch.cuda.synchronize()
             lat.append(e0.elapsed_time(e1))
         result["ttft_ms_single_clip"] = float(np.median(lat))
+        hl = []
+        for _ in range(3):                                            # the same, on the host clock, including the read-back of the slot state
+            torch.cuda.synchronize()
+            t_h = time.perf_counter()
+            vis = eng.vit_encode(pixels[:F], r)
+            eng.begin_batch(1, N, None)
+            emb, L = eng.project_splice(vis, ids[0])
+            eng.prefill(0, emb, L)
+            lens_h, _ = eng.slot_state()
+            hl.append(1e3 * (time.perf_counter() - t_h))
+            assert int(lens_h[0]) == 1
+        result["ttft_host_ms_single_clip"] = float(np.median(hl))
 
     eng.close()
     del eng

@@ -190,3 +190,26 @@ def test_cu_mask_words_enable_k_cus_of_every_xcd():
         cu_mask_words(0)
     with pytest.raises(ValueError):
         cu_mask_words(33)
+
+
+def test_bench_config_presets_name_the_baseline_configs(monkeypatch):
+    """`bench.py --config cfgN` = BASELINE.json configs[N-1]; explicit flags win; the default is configs[1]."""
+    import json as _json
+    import sys as _sys
+    import bench
+    base = _json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))["configs"]
+    for name, c in bench.CONFIGS.items():
+        txt = base[c["index"]]
+        st = c["set"]
+        assert f"{st['num_frm']}-frame" in txt, (name, txt)
+        if "token_kept_ratio=" in txt or "r=" in txt:
+            assert (f"token_kept_ratio={st['token_kept_ratio']}" in txt) or (f"r={st['token_kept_ratio']}" in txt), (name, txt)
+        if "tokens" in txt:
+            assert f"{st['max_new_tokens']} tokens" in txt, (name, txt)
+    assert bench.CONFIGS["cfg4"]["set"]["batch"] * 8 == 64                      # "batch of 64 clips sharded 8-way"
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--config", "cfg5", "--batch", "7"])
+    a = bench.parse()
+    assert (a.num_frm, a.token_kept_ratio, a.max_new_tokens, a.batch) == (8, 0.8, 2048, 7)
+    monkeypatch.setattr(_sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.num_frm, a.token_kept_ratio, a.max_new_tokens, a.batch, a.config_name) == (8, 0.3, 256, 128, "cfg2")

@@ -94,3 +94,44 @@ def test_loader_brings_torch_hip_runtime_first():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "torch" in out.stdout, out.stdout
+
+
+def _header_config_fields():
+    """[(name, 'int32_t' | 'float'), ...] of struct aur_config, in declaration order, parsed from include/aurora_hip.h"""
+    import re
+    src = open(os.path.join(ROOT, "include", "aurora_hip.h")).read()
+    body = src[src.index("typedef struct aur_config {") + len("typedef struct aur_config {"):src.index("} aur_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        ctype, names = decl.split(" ", 1)
+        assert ctype in ("int32_t", "float"), decl
+        fields += [(n.strip(), ctype) for n in names.split(",")]
+    return fields
+
+
+def test_documented_ctypes_stub_matches_the_header():
+    """INTEGRATION.md's `AurConfig` stub is what a maintainer copies: its fields (names, order, widths) and its example
+    initialiser must match struct aur_config in include/aurora_hip.h - and so must aurora_amd/_lib.py (the stub had
+    fallen one field behind the header, which shifts every later read of aur_create)."""
+    import ctypes as C
+    import re
+    from aurora_amd import _lib
+    want = _header_config_fields()
+    ct = {"int32_t": C.c_int32, "float": C.c_float}
+    assert [(n, t) for n, t in _lib.AurConfig._fields_] == [(n, ct[t]) for n, t in want]
+    assert C.sizeof(_lib.AurConfig) == 4 * len(want)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = doc.index("class AurConfig(C.Structure):")
+    block = doc[start:doc.index("\n\n", start)]
+    ns = {"C": C}
+    exec(block, ns)                                                # the documented class itself
+    assert [(n, t) for n, t in ns["AurConfig"]._fields_] == [(n, ct[t]) for n, t in want]
+    init = re.search(r"cfg = AurConfig\(([^)]*)\)", doc).group(1)
+    vals = [v.strip() for v in init.split(",")]
+    assert len(vals) == len(want), (len(vals), len(want))
+    cfg = ns["AurConfig"](*[float(v) if t == "float" else int(v) for v, (_, t) in zip(vals, want)])
+    assert cfg.vit_image == 378 and cfg.llm_vocab == 32000 and cfg.page_tokens == 64 and cfg.spare_slots == 0
