@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libaurora_hip.so")
+# AURORA_HIP_SO selects another build of the same library (the host-sanitizer build of aurora_amd/build.py, tests/test_asan_host.py)
+SO_PATH = os.environ.get("AURORA_HIP_SO") or os.path.join(HERE, "libaurora_hip.so")
 
 AUR_ACT_QUICK_GELU = 1
 AUR_ACT_GELU = 2

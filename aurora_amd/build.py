@@ -39,16 +39,36 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+# Host-side sanitizer build (ASan/UBSan over the C-ABI host layer): the same sources with AddressSanitizer and
+# UndefinedBehaviorSanitizer on the HOST code only (-fno-gpu-sanitize: the gfx950 code objects are the product's), linked against
+# the shared ASan runtime so that an un-instrumented python can load it with LD_PRELOAD=<asan_runtime()>.  tests/test_asan_host.py.
+OUT_ASAN = os.path.join(HERE, "libaurora_hip_asan.so")
+SAN = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
+
+
+def asan_runtime() -> str:
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[-1]
+
+
+def build(force: bool = False, verbose: bool = True, sanitize: bool = False) -> str:
+    out = OUT_ASAN if sanitize else OUT
+    if sanitize:
+        if not force and os.path.exists(out) and all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(out) for f in os.listdir(CSRC)):
+            return out
+    elif not force and not needs_build():
         return OUT
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_asan" if sanitize else "build")
     os.makedirs(objdir, exist_ok=True)
+    common = [c if c != "-O3" else "-O1" for c in COMMON] + SAN if sanitize else COMMON
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *COMMON, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *common, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-6000:]}")
@@ -58,14 +78,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(SAN if sanitize else []), "-o", out, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     if verbose:
-        print(f"built {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB)")
-    return OUT
+        print(f"built {out} ({os.path.getsize(out) / 1e6:.1f} MB)")
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv)

@@ -286,3 +286,46 @@ def test_gemm_tile_orders_agree_bitwise(eng):
         eng.set_option("gemm_tail_split", 1)
         eng.set_option("gemm_max_wgs", 0)
         eng.set_option("gemm_mode", 1)
+
+
+def test_tome_match_hand_over_stress_alone_and_beside_a_decode_stream():
+    """The match -> select hand-over of tome_match_kernel (per-frame arrival counter, `sc1` payload, drained vmcnt, `sc1` loads in
+    the last workgroup - not a HIP-memory-model release/acquire pair: ADVICE r2) under the conditions that expose a stale read:
+    many frames (uneven arrival: 64 frames x 12 workgroups over 256 CUs), many layers' worth of shapes, repeated, and the same next
+    to a bandwidth-hungry stream on the other CUs.  Every run must reproduce the C oracle's indices bit for bit."""
+    from aurora_amd.engine import AuroraCapEngine
+    cfg = {"vit": dict(hidden_size=1280, num_attention_heads=16, num_hidden_layers=2, intermediate_size=256, patch_size=14,
+                       image_size=378, hidden_act="quick_gelu"), "llm": None}
+    eng = AuroraCapEngine(cfg, {}, max_frames=64, max_batch=1, max_ctx=128, max_new_tokens=8)
+    try:
+        gen = torch.Generator().manual_seed(31)
+        shapes = [(730, 15), (715, 15), (505, 15), (385, 15), (295, 15), (280, 15), (33, 15), (17, 8)]      # t, r over the 31 layers' range
+        cases = []
+        for t, r in shapes:
+            metric = torch.randn(64, t, 80, generator=gen)
+            metric[:, 5] = metric[:, 3]                                   # exact ties inside every frame
+            metric[:, 8] = metric[:, 6] * 2.0                             # equal after normalisation
+            x = torch.randn(64, t, 64, generator=gen).half()
+            want = tome_ref.match(metric.numpy(), r)
+            cases.append((metric, x, r, want))
+
+        def sweep(reps):
+            for _ in range(reps):
+                for metric, x, r, want in cases:
+                    _, _, idx = eng.tome_step(metric, x, None, r)
+                    for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+                        np.testing.assert_array_equal(idx[k].cpu().numpy(), want[k], err_msg=f"{k} t={metric.shape[1]}")
+
+        sweep(20)
+        # the same beside a stream that keeps the memory system busy (what the serving schedule does to the ViT)
+        big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
+        side = torch.cuda.Stream()
+        stop = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            for _ in range(400):
+                big.add_(1.0)
+            stop.record()
+        sweep(10)
+        torch.cuda.synchronize()
+    finally:
+        eng.close()

@@ -143,5 +143,4 @@ def test_read_video_pyav_falls_back_to_packet_decode(monkeypatch):
     # header promises more frames than exist: the reference returns the frames its stream walk found (indices 12 and 19 never turn
     # up among 12 frames) - record_video_length_stream, load_video.py:7-16 - without re-sampling
     assert frames_of("clip.mp4", 12, 20) == [0, 6]
-    assert frames_of("clip.mp4", 0, 20) == []  if False else True             # (an empty stream falls back to packet decode: covered by the header-0 case)
     assert frames_of("clip.webm", 20, 20) == want and frames_of("clip.mkv", 20, 20) == want
