@@ -43,28 +43,34 @@ def needs_build() -> bool:
 # UndefinedBehaviorSanitizer on the HOST code only (-fno-gpu-sanitize: the gfx950 code objects are the product's), linked against
 # the shared ASan runtime so that an un-instrumented python can load it with LD_PRELOAD=<asan_runtime()>.  tests/test_asan_host.py.
 OUT_ASAN = os.path.join(HERE, "libaurora_hip_asan.so")
+OUT_UBSAN = os.path.join(HERE, "libaurora_hip_ubsan.so")        # UBSan alone: no preload, coexists with the HIP runtime on a GPU box
 SAN = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
+SAN_UB = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
 
 
-def asan_runtime() -> str:
+def asan_runtime(name: str = "asan") -> str:
+    """shared sanitizer runtime to LD_PRELOAD into an un-instrumented python: "asan" or "ubsan_standalone" """
     import glob
-    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    hits = sorted(glob.glob(f"/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.{name}-x86_64.so"))
     if not hits:
-        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+        raise RuntimeError(f"libclang_rt.{name}-x86_64.so not found under /opt/rocm/lib/llvm")
     return hits[-1]
 
 
-def build(force: bool = False, verbose: bool = True, sanitize: bool = False) -> str:
-    out = OUT_ASAN if sanitize else OUT
+def build(force: bool = False, verbose: bool = True, sanitize=False) -> str:
+    """sanitize: False (the product), True / "asan" (ASan + UBSan on the host code), "ubsan" (UBSan only, traps made fatal)"""
+    ub = sanitize == "ubsan"
+    out = OUT_UBSAN if ub else (OUT_ASAN if sanitize else OUT)
+    san = SAN_UB if ub else SAN
     if sanitize:
         if not force and os.path.exists(out) and all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(out) for f in os.listdir(CSRC)):
             return out
     elif not force and not needs_build():
         return OUT
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build_asan" if sanitize else "build")
+    objdir = os.path.join(HERE, ("build_ubsan" if ub else "build_asan") if sanitize else "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [c if c != "-O3" else "-O1" for c in COMMON] + SAN if sanitize else COMMON
+    common = [c if c != "-O3" else "-O1" for c in COMMON] + san if sanitize else COMMON
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -78,7 +84,7 @@ def build(force: bool = False, verbose: bool = True, sanitize: bool = False) -> 
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(SAN if sanitize else []), "-o", out, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(san if sanitize else []), "-o", out, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
@@ -88,4 +94,4 @@ def build(force: bool = False, verbose: bool = True, sanitize: bool = False) -> 
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv)
+    build(force="--force" in sys.argv, sanitize="ubsan" if "--ubsan" in sys.argv else ("--sanitize" in sys.argv))

@@ -304,7 +304,7 @@ def main():
     plans = [eng.splice_plan(ids[b], F, n_kept) for b in range(B)]   # static per prompt: uploaded once, outside the loop
     torch.cuda.synchronize()
     ttft_ms = []
-    host_ttft = []
+    host_ttft, submit_ttft = [], []
 
     def front(bank, record_ttft=False):
         """ViT + projector/splice + prefill of one batch into generation bank `bank` (enqueue only)."""
@@ -462,19 +462,38 @@ def main():
             first_dev = torch.zeros(NG, G, N, dtype=torch.int32, device=dev)
             first_len = torch.zeros(NG, G, dtype=torch.int32, device=dev)
             first_host = torch.zeros(NG, G, dtype=torch.int32).pin_memory()
-            host_q = queue.Queue()
+            host_q, start_q, start_stamp = queue.Queue(), queue.Queue(), {}
+
+            def start_poller():                                   # host clock at which a group's front end STARTED on the device
+                while True:
+                    item = start_q.get()
+                    if item is None:
+                        return
+                    key, ev = item
+                    ev.synchronize()
+                    start_stamp[key] = time.perf_counter()
 
             def poller():
                 while True:
                     item = host_q.get()
                     if item is None:
                         return
-                    t_submit, ev = item
+                    key, t_submit, ev = item
                     ev.synchronize()
-                    host_ttft.append(1e3 * (time.perf_counter() - t_submit))
+                    now = time.perf_counter()
+                    submit_ttft.append(1e3 * (now - t_submit))
+                    for _ in range(200):                          # the start stamp comes from the other helper thread
+                        if key in start_stamp:
+                            break
+                        time.sleep(0.001)
+                    if key in start_stamp:
+                        host_ttft.append(1e3 * (now - start_stamp[key]))
 
             poll_thread = threading.Thread(target=poller, daemon=True)
+            start_thread = threading.Thread(target=start_poller, daemon=True)
             poll_thread.start()
+            start_thread.start()
+            front_seq = [0]
 
             def front_async(g):
                 t_host = time.perf_counter()
@@ -487,7 +506,9 @@ def main():
                     eng.prefill_stage(B, G, emb_all, L0)
                     evf = torch.cuda.Event()
                     evf.record(sF)
-                return e0, evf, t_host
+                front_seq[0] += 1
+                start_q.put((front_seq[0], e0))
+                return e0, evf, (front_seq[0], t_host)
 
             def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
                 for g in range(NG):
@@ -505,7 +526,7 @@ def main():
                             first_host[g].copy_(first_dev[g, :, 0], non_blocking=True)
                             e2 = torch.cuda.Event()
                             e2.record(sC)
-                        host_q.put((t_host, e2))
+                        host_q.put((t_host[0], t_host[1], e2))
                     # the chunk's decode is enqueued BEFORE the next front end (a few hundred launches on the host): both wait for
                     # the commit only, and the decode must never sit behind the host's enqueue time
                     n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
@@ -550,7 +571,9 @@ def main():
         ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
         if overlap:
             host_q.put(None)
+            start_q.put(None)
             poll_thread.join()
+            start_thread.join()
             # the copied first ids are the captions' first ids (the read-back is real, not a timestamp of nothing)
             assert all(int(first_host[g, j]) == batch_ref[g * G + j][0] for g in range(NG) for j in range(G)), "host read-back of the first tokens disagrees"
     elif not pipe:
@@ -665,9 +688,12 @@ def main():
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
-            "ttft_host_note": ("host clock from the submission of a group's front end to its first token ids sitting in pinned host memory (a side "
-                               "stream copies them after the commit; a helper thread waits for the copy), same cycles as the timed region"
-                               if (continuous and overlap) else None),
+            "ttft_host_note": ("host clock from the moment a group's front end STARTS on the device (a helper thread waits for its first event) to its "
+                               "first token ids sitting in pinned host memory (a side stream copies them after the commit; a second helper thread "
+                               "waits for the copy), same cycles as the timed region.  p50_submit_to_first_token_host_ms starts the clock at the host "
+                               "call that SUBMITS the front end instead: this benchmark enqueues a whole cycle ahead of the device, so that figure "
+                               "is dominated by its own queue depth, not by the path" if (continuous and overlap) else None),
+            "p50_submit_to_first_token_host_ms": (float(np.median(submit_ttft)) if (continuous and overlap and submit_ttft) else None),
             "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "
                            "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1)
                            + ("; the front end runs on the front-end stream during the chunk before the group's boundary and its first tokens "

@@ -52,3 +52,32 @@ extern "C" int lab_stream_launch(void* stream, const void* p, int64_t bytes, int
     else hipLaunchKernelGGL(lab_stream_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f4v*)p, bytes / 16, reps, sink);
     return (int)hipGetLastError();
 }
+
+// ---- the same bytes read by all 8 XCDs: does the memory-side cache turn 8 reads into 1 HBM read?  Every XCD's workgroups
+// (blockIdx % 8 = XCD) jointly sweep the WHOLE buffer once, XCD x starting `stagger` bytes ahead of XCD x - 1 (wrapping).
+// stagger = 0: all XCDs ask for the same lines at the same moment (what a GEMM round shared by the XCDs does); stagger > 0: XCD x
+// re-reads what XCD x + 1 fetched `stagger` bytes of streaming earlier (a software-pipelined hand-down of operand tiles).
+__global__ __launch_bounds__(256) void lab_share_kernel(const f4v* __restrict__ p, int64_t n16, int64_t stagger16, float* sink) {
+    const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, nw = gridDim.x >> 3;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    const int64_t start = (int64_t)xcd * stagger16;
+    for (int64_t i = (int64_t)wi * 256 + threadIdx.x; i < n16; i += (int64_t)nw * 256 * 4) {
+        f4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t j = i + (int64_t)u * nw * 256;
+            if (j < n16) {
+                j += start;
+                j = j >= n16 ? j - n16 : j;
+                v[u] = p[j];
+            } else v[u] = f4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    if (acc.x == 1.2345f) sink[0] = acc.y + acc.z + acc.w;
+}
+extern "C" int lab_share_launch(void* stream, const void* p, int64_t bytes, int64_t stagger_bytes, int blocks, float* sink) {
+    hipLaunchKernelGGL(lab_share_kernel, dim3(blocks & ~7), dim3(256), 0, (hipStream_t)stream, (const f4v*)p, bytes / 16, stagger_bytes / 16, sink);
+    return (int)hipGetLastError();
+}
