@@ -1140,7 +1140,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
         else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
         else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
-        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = value ? 1 : 0;
+        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value >= 0 && value <= 2) ? (int)value : 1;
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
         else if (!strcmp(name, "gemm_lab")) ctx->gemm_lab = (value >= 0 && value <= 7) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only
         else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;

@@ -309,9 +309,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     // are 4 (M) x 8 (N) and nothing is shared between XCDs in time.  gridDim.x is a multiple of 8 whenever a workgroup walks more than
     // one tile, so its tiles keep the XCD (bid % 8) both orders assume.
     TileOrder ord;
-    tile_order_init(ord, nbm, nbn, a.tile_order == 1 ? (int)gridDim.x : 0);
+    tile_order_init(ord, nbm, nbn, a.tile_order >= 1 ? (int)gridDim.x : 0, a.tile_order == 2 ? 2 : 1);
     auto tile_of = [&](int bid, int& bm, int& bn) {
-        if (ord.full > 0 || a.tile_order == 1) {
+        if (ord.full > 0 || a.tile_order >= 1) {
             tile_of_bid(ord, bid, bm, bn);
             return;
         }

@@ -33,7 +33,8 @@ struct GemmArgs {
     int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
     int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
     int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
-    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
+    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges,
+                            // 2 = hand-down: an XCD keeps its band of M-tiles, weight column groups pass from XCD to XCD round by round
     int lab;                // 0 in the product path; > 0 = lab instantiation of the 256x256 kernel (gemm256.hip G2Lab, EPI_ROW only)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent

@@ -334,3 +334,33 @@ def test_vit_h_free_running_index_audit():
             assert drift < 5e-3, drift
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name,frames,ratio,kept", [("cfg3", 16, 0.2, 171), ("cfg5", 8, 0.8, 605)])
+def test_full_size_cfg3_and_cfg5_at_their_own_ratios(name, frames, ratio, kept):
+    """BASELINE configs[2] (16 frames, ratio 0.2 -> r = 18, 171 tokens per frame) and configs[4] (8 frames, ratio 0.8 -> r = 4, 605
+    tokens per frame, prefix 4870) at FULL size and at THEIR OWN merge ratios (the full-size property test used ratio
+    0.3 for its 16-frame clip): token schedule as the reference computes it, a batch of two clips == each clip alone == a repeat,
+    the overlapped continuous-batching stream == the same, 8 greedy tokens, ids inside the vocabulary."""
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine, tokens_at_layer
+    cfg = S.AURORACAP_7B
+    w = {"vit": S.vit_weights(cfg["vit"]), "projector": S.projector_weights(1280, 4096), "llm": S.llm_weights(cfg["llm"])}
+    L0 = 30 + frames * kept
+    eng = AuroraCapEngine(cfg, w, max_frames=2 * frames, max_batch=2, max_ctx=-(-(L0 + 8) // 64) * 64, max_new_tokens=8, spare_slots=1)
+    del w
+    torch.cuda.empty_cache()
+    try:
+        r = eng.tome_r(ratio)
+        assert tokens_at_layer(730, r, 31) - 1 == kept
+        clips = [(S.frames(frames, 20 + i), S.prompt_ids(frames, 20 + i)) for i in range(2)]
+        vis = eng.vit_encode(clips[0][0], r)
+        assert tuple(vis.shape) == (frames, kept, 1280)
+        alone = [eng.caption_ids(px, ids, ratio, 8, eos_id=None) for px, ids in clips]
+        assert all(len(a) == 8 and all(0 <= t < 32000 for t in a) for a in alone) and alone[0] != alone[1]
+        assert eng.caption_batch(clips, ratio, 8, eos_id=None) == alone
+        assert eng.caption_batch(clips, ratio, 8, eos_id=None) == alone
+        got = dict(eng.caption_stream(clips + clips[:1], ratio, 8, eos_id=None, check_every=4))      # front ends prefetched beside the decode
+        assert [got[i] for i in range(3)] == alone + alone[:1]
+    finally:
+        eng.close()

@@ -121,14 +121,14 @@ def main():
     print("# together: decode kernel on the decode stream, GEMM variant on the front-end stream (us, and ratio to alone)", flush=True)
     dks = ("dec_attn",) if quick else ("dec_attn", "dec_gateup", "dec_qkv", "dec_down")
     for dk in dks:
-        for lab in LAB:
+        for lab in (LAB if not quick else ()):
             eng.set_option("gemm_lab", lab)
             r = pair(dk, sd, "pre_gateup", sf, alone[dk], galone[lab])
             print(f"{dk:11s} {r['x']:8.1f} us ({r['x'] / alone[dk]:4.2f}x) | pre_gateup [{lab} {LAB[lab]:8s}] {r['y']:8.1f} us ({r['y'] / galone[lab]:4.2f}x) | "
                   f"clock {r['mhz']:.0f} MHz", flush=True)
     # default-policy KV loads against the product GEMM and the nt GEMM
     eng.set_option("dec_attn_variant", 2)
-    for lab in (0, 3):
+    for lab in ((0, 3) if not quick else ()):
         eng.set_option("gemm_lab", lab)
         r = pair("dec_attn", sd, "pre_gateup", sf, alone["dec_attn_plain"], galone[lab])
         print(f"dec_attn(plain KV loads) {r['x']:8.1f} us ({r['x'] / alone['dec_attn_plain']:4.2f}x) | pre_gateup [{lab} {LAB[lab]:8s}] {r['y']:8.1f} us "
@@ -136,18 +136,20 @@ def main():
     eng.set_option("dec_attn_variant", 1)
     eng.set_option("gemm_lab", 0)
     # the other front-end kernels beside the decode attention
-    for fk in ("pre_attn", "pre_qkv", "pre_down", "pre_o"):
+    for fk in (("pre_attn", "pre_qkv", "pre_down", "pre_o") if not quick else ()):
         if fk not in alone:
             alone[fk] = mb(fk, sf, 100)
         r = pair("dec_attn", sd, fk, sf, alone["dec_attn"], alone[fk])
         print(f"dec_attn    {r['x']:8.1f} us ({r['x'] / alone['dec_attn']:4.2f}x) | {fk:10s} {r['y']:8.1f} us ({r['y'] / alone[fk]:4.2f}x, alone {alone[fk]:.1f}) | clock {r['mhz']:.0f} MHz",
               flush=True)
-    # tile order of the product GEMM beside the decode attention
-    for order in (0, 1):
-        eng.set_option("gemm_tile_order", order)
-        ga = mb("pre_gateup", sf, 120)
-        r = pair("dec_attn", sd, "pre_gateup", sf, alone["dec_attn"], ga)
-        print(f"tile_order {order}: dec_attn {r['x']:8.1f} us ({r['x'] / alone['dec_attn']:4.2f}x) | pre_gateup {r['y']:8.1f} us (alone {ga:.1f})", flush=True)
+    # tile order of the product GEMM beside the decode attention (0 per-XCD ranges, 1 compact shared blocks, 2 hand-down)
+    for fk in ("pre_gateup", "pre_qkv", "pre_down", "pre_o"):
+        for order in (0, 1, 2):
+            eng.set_option("gemm_tile_order", order)
+            ga = mb(fk, sf, 120)
+            r = pair("dec_attn", sd, fk, sf, alone["dec_attn"], ga)
+            print(f"tile_order {order}: dec_attn {r['x']:8.1f} us ({r['x'] / alone['dec_attn']:4.2f}x) | {fk:10s} {r['y']:8.1f} us (alone {ga:.1f})", flush=True)
+    eng.set_option("gemm_tile_order", 1)
     eng.close()
 
 
