@@ -1,0 +1,85 @@
+"""Is the mutual slow-down of the two CU-masked streams a POWER effect?  Samples `rocm-smi` (socket power, sclk) while the decode
+attention runs alone on the top 16 CUs of every XCD, the prefill gate/up GEMM alone on the bottom 16 (product and no-DMA form), and
+both together.  (lab tool)
+
+    python tools/cumask/power_lab.py [B]
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from aurora_amd import synthetic as S                     # noqa: E402
+from aurora_amd.engine import AuroraCapEngine, _rup       # noqa: E402
+from aurora_amd.streams import cu_masked_stream           # noqa: E402
+
+
+def smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out)
+        card = d[sorted(d)[0]]
+        pw = next((v for k, v in card.items() if "ower" in k and "(W)" in k), None)
+        sclk = next((v for k, v in card.items() if k.lower().startswith("sclk")), None)
+        mclk = next((v for k, v in card.items() if k.lower().startswith("mclk")), None)
+        fclk = next((v for k, v in card.items() if k.lower().startswith("fclk")), None)
+        return pw, sclk, mclk, fclk
+    except Exception as e:                                 # noqa: BLE001
+        return ("err", repr(e)[:80], None, None)
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
+    l = S.VICUNA_7B_16K
+    L0 = 2142
+    eng = AuroraCapEngine({"vit": None, "llm": l}, {"llm": S.llm_weights(l)}, max_frames=1, max_batch=B, max_ctx=_rup(L0 + 256, 64), max_new_tokens=256)
+    torch.cuda.empty_cache()
+    eng.begin_batch(B, 256, None)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    emb0 = (torch.randn(_rup(L0, 32), l["hidden_size"], generator=g, device="cuda") * 0.02).half()
+    for b in range(B):
+        eng.prefill(b, emb0.clone(), L0)
+    torch.cuda.synchronize()
+    eng.set_option("microbench_prefill_nseq", 4)
+    sd, sf, sa = cu_masked_stream(16, from_top=True), cu_masked_stream(16), torch.cuda.Stream()
+    print("idle:", smi(), flush=True)
+
+    def mb(kernel, stream, iters, box, key):
+        with torch.cuda.stream(stream):
+            box[key] = eng.microbench(kernel, iters)
+
+    def run(jobs, label):
+        box = {}
+        ths = [threading.Thread(target=mb, args=(k, st, it, box, k + str(i))) for i, (k, st, it) in enumerate(jobs)]
+        for t in ths:
+            t.start()
+        samples = []
+        time.sleep(0.5)
+        for _ in range(4):
+            samples.append(smi())
+            time.sleep(0.3)
+        for t in ths:
+            t.join()
+        print(f"{label:60s} us: " + ", ".join(f"{k} {v:.1f}" for k, v in box.items()) + " | smi (W, sclk, mclk, fclk): " + " ".join(str(s) for s in samples), flush=True)
+
+    eng.set_option("gemm_max_wgs", 128)
+    run([("dec_attn", sd, 5000)], "decode attention alone, top 16 CUs per XCD")
+    for lab, name in ((0, "product"), (5, "no operand DMA")):
+        eng.set_option("gemm_lab", lab)
+        run([("pre_gateup", sf, 2200)], f"prefill gate/up [{name}] alone, bottom 16 CUs per XCD")
+        run([("dec_attn", sd, 5500), ("pre_gateup", sf, 1800)], f"both: decode attention + gate/up [{name}]")
+    eng.set_option("gemm_lab", 0)
+    eng.set_option("gemm_max_wgs", 0)
+    run([("pre_gateup", sa, 3000)], "prefill gate/up alone on ALL CUs")
+    run([("dec_attn", sa, 5000)], "decode attention alone on ALL CUs")
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
