@@ -1048,6 +1048,123 @@ __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
     }
 }
 
+// Variant 3: the same page pipeline with HALF the register footprint -> two waves per SIMD.  decode_attn_pipe_kernel double-buffers K
+// in registers (kf + kn + vf = 192 VGPRs of operands: 290 with the rest, one wave per SIMD, 128 KiB of loads in flight per CU).  On the
+// 16 CUs per XCD the decode stream owns while a front end runs, the kernel is bound by bytes in flight per CU (6.4 TB/s on 128 CUs against
+// 7.3 TB/s on 256), so this variant re-loads K(p + 1) into the SAME registers as soon as the Q K^T products of page p have been issued:
+// the loads have the softmax and the P V products of page p to land.  128 VGPRs of operands, <= 256 in all, 8 waves per CU, up to 256 KiB in
+// flight.  Same operations in the same order: bitwise the result of variant 1.
+template <int KBLK, int VD16>
+__global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;
+    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const KvLayout& kv = a.kv;
+    const int npos = a.pos[b] + 1;
+    const int seq = a.seq_ids ? a.seq_ids[b] : b;
+    const int npages = (npos + 63) >> 6;
+    const int p_first = sp * a.pages_per_split;
+    int p_last = p_first + a.pages_per_split;
+    p_last = p_last < npages ? p_last : npages;
+    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
+
+    h8 qf[KBLK];
+#pragma unroll
+    for (int blk = 0; blk < KBLK; ++blk)
+        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
+    f4 acc_o[VD16];
+#pragma unroll
+    for (int d = 0; d < VD16; ++d) acc_o[d] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale * 1.4426950408889634f;
+    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;
+    const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;
+
+    h8 kf[4 * KBLK];
+    if (p_first < p_last) {
+        const half_t* page = kv_page(kv, seq, p_first * 64);
+#pragma unroll
+        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
+    }
+    for (int p = p_first; p < p_last; ++p) {
+        const half_t* page = kv_page(kv, seq, p * 64);
+        h8 vf[VD16 * 2];
+#pragma unroll
+        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
+        const bool more = p + 1 < p_last;                 // wave-uniform
+        const int key0 = p * 64;
+        f4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < KBLK; ++blk) s[kt] = mfma16(kf[kt * KBLK + blk], qf[blk], s[kt]);
+        }
+        if (more) {                                       // K of the next page into the registers the products above have just read
+            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = key0 + kt * 16 + 4 * g + i;
+                const float v = key < npos ? s[kt][i] * sc : -INFINITY;
+                s[kt][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        h8 pf[2];
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][i] - m_new);
+                ps += pv;
+                pf[kt >> 1][(kt & 1) * 4 + i] = (half_t)pv;
+            }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_o[d][i] *= alpha;
+            acc_o[d] = mfma16(vf[d * 2 + 0], pf[0], acc_o[d]);
+            acc_o[d] = mfma16(vf[d * 2 + 1], pf[1], acc_o[d]);
+        }
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (a.nsplit == 1) {
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int d = 0; d < VD16; ++d) {
+                const int k = head * a.hd + d * 16 + 4 * g;
+                h4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc_o[d][i] / l);
+                *(h4*)(a.out_f + xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)) = o;
+            }
+        }
+        return;
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
+    }
+    if (lane == 0) {
+        a.part_ml[pidx * 2 + 0] = m_run;
+        a.part_ml[pidx * 2 + 1] = l;
+    }
+}
+
 __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     if (d >= a.hd) return;
@@ -1071,6 +1188,7 @@ hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     dim3 grid(a.nsplit, a.heads, a.B);
     const bool pipe = a.variant >= 1 && a.kv.page_tokens == 64;
     if (a.variant == 2 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8, false>), grid, dim3(64), 0, s, a);
+    else if (a.variant == 3 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe2_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_pipe_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_pipe_kernel<1, 2>), grid, dim3(64), 0, s, a);

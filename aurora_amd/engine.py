@@ -124,11 +124,7 @@ class AuroraCapEngine:
             torch.cuda.synchronize()
             self.L.aur_destroy(self.ctx)
             self.ctx = None
-            for pair in getattr(self, "_masked", {}).values():      # CU-masked streams of caption_stream(overlap=True)
-                for st in pair:
-                    from .streams import destroy_stream
-                    destroy_stream(st)
-            self._masked = {}
+            self._masked = {}                                       # CU-masked streams are shared per process (streams.py): never destroyed
             if torch.cuda.current_stream(self.dev) == self.stream:
                 torch.cuda.set_stream(self._prev_stream)
 
@@ -562,13 +558,13 @@ class AuroraCapEngine:
                     owner[s] = None
 
     def _masked_streams(self, front_cus: int):
-        """(front-end stream on `front_cus` CUs of every XCD, decode stream on the other CUs), created once per engine."""
-        from .streams import cu_masked_stream
+        """(front-end stream on `front_cus` CUs of every XCD, decode stream on the other CUs); shared per process (streams.py)."""
+        from .streams import shared_cu_masked_stream
         if not hasattr(self, "_masked"):
             self._masked = {}
         if front_cus not in self._masked:
-            self._masked[front_cus] = (cu_masked_stream(front_cus, device=self.dev),
-                                       cu_masked_stream(32 - front_cus, from_top=True, device=self.dev))
+            self._masked[front_cus] = (shared_cu_masked_stream(front_cus, device=self.dev),
+                                       shared_cu_masked_stream(32 - front_cus, from_top=True, device=self.dev))
         return self._masked[front_cus]
 
     def _caption_stream_overlapped(self, clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus):

@@ -40,8 +40,26 @@ def cu_mask_words(cus_per_xcd: int, from_top: bool = False, xcds: int = 8, cus_i
     return words
 
 
+_CACHE = {}
+
+
+def shared_cu_masked_stream(cus_per_xcd: int, from_top: bool = False, device=None) -> "torch.cuda.ExternalStream":
+    """One CU-masked stream per (device, CUs, end) for the life of the process - what engines use.  torch's caching allocator
+    remembers every stream a tensor was `record_stream`-ed on and records an event there when the tensor is freed, possibly long
+    after the engine that ran on the stream is gone: a stream that tensors have been recorded on must never be destroyed (a
+    destroyed one made the interpreter segfault when the clips of a finished caption_stream were garbage-collected)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, int(cus_per_xcd), bool(from_top))
+    if key not in _CACHE:
+        _CACHE[key] = cu_masked_stream(cus_per_xcd, from_top, dev)
+    return _CACHE[key]
+
+
 def destroy_stream(stream: "torch.cuda.ExternalStream") -> None:
-    """Release a stream made by `cu_masked_stream` (the wrapper does not own it).  The caller has synchronised it."""
+    """Release a stream made by `cu_masked_stream` (the wrapper does not own it).  The caller has synchronised it AND no tensor
+    was ever `record_stream`-ed on it (see shared_cu_masked_stream)."""
     _runtime().hipStreamDestroy(C.c_void_p(stream.cuda_stream))
 
 

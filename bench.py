@@ -726,9 +726,14 @@ def main():
         how = "HIP events around every launch of this kernel in one extra eager, un-pipelined step on the launch stream (after the timed steps)"
         # rocprofv3 --pmc summary of this same command (tools/profile_round.sh -> profiles/r02_pmc.json), if committed: per-kernel
         # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE KiB, separate passes) measured at 6 new tokens, scaled to this run below
-        pmc, pmc_ctx = {}, None
+        pmc, pmc_ctx, pmc_tag = {}, None, "r02"
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            pj = None
+            for tag in ("r03", "r02"):                                 # the newest committed counter summary
+                fp = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+                if os.path.exists(fp):
+                    pj, pmc_tag = json.load(open(fp)), tag
+                    break
             pmc_ctx = pj.get("_batch_x_ctx")
             for ent in pj["kernels"]:
                 if "hbm_bytes_per_launch" in ent:
@@ -747,16 +752,18 @@ def main():
                                    "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
                                    "traffic": (pmc_of("decode_attn_pipe_kernel")["hbm_bytes_per_launch"] * (B * mean_ctx) / pmc_ctx)
                                    if (pmc_of("decode_attn_pipe_kernel") and pmc_ctx) else None,
-                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/r02_pmc.json (separate passes of this "
-                                                   "command at 6 new tokens), scaled linearly from its batch x context to this run's",
+                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/%s_pmc.json (separate passes of this command at "
+                                                   "the same batch and 6 new tokens), scaled by (this run's mean context) / (the pass's context) = %.3f"
+                                                   % (pmc_tag, (B * mean_ctx) / pmc_ctx if pmc_ctx else float("nan")),
                                    "algorithmic_bytes_per_launch": alg,
                                    "avg_launch_us": avg_s * 1e6, "launches_timed": an, "how": how}
         if kn > 0:
             alg = 2 * mlp * d * 2 + B * d * 2 + B * mlp * 2           # gate+up rows fp16 + x in + h out
             avg_s = kms / kn * 1e-3
-            roof["decode_gateup"] = {"bound": "hbm", "kernel": "skinny_lds_kernel<6, 2, SK_SILU_MUL> (decode gate/up projection, x through LDS)",
+            gu_name = "skinny_lds_kernel<6, 1, 2" if eng.max_batch > 64 else "skinny_lds_kernel<6, 2, 2"     # k phases per tile: a constant of the engine
+            roof["decode_gateup"] = {"bound": "hbm", "kernel": gu_name + ", ...> (decode gate/up projection, x through LDS)",
                                      "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                     "traffic": pmc_of("skinny_lds_kernel<6, 2, 2")["hbm_bytes_per_launch"] if pmc_of("skinny_lds_kernel<6, 2, 2") else None,
+                                     "traffic": pmc_of(gu_name)["hbm_bytes_per_launch"] if pmc_of(gu_name) else None,
                                      "algorithmic_bytes_per_launch": alg,
                                      "avg_launch_us": avg_s * 1e6, "launches_timed": kn, "how": how}
         if roof:    # the dominant kernel = the one with the larger total time in the decode loop

@@ -264,3 +264,31 @@ def test_single_split_decode_attention_finishes_in_the_kernel(name):
         finally:
             eng.close()
     assert outs[False] == outs[True]
+
+
+def test_decode_attention_variants_are_bitwise_equal():
+    """dec_attn_variant 3 (K re-loaded into the same registers once the Q K^T products of a page are issued: two waves per SIMD,
+    twice the loads in flight per CU) performs the operations of variant 1 in the same order: logits and ids must be bitwise
+    equal, single split (large batch) and multi-split (batch 1) alike, head_dim 128."""
+    cfg = LLM_CFGS["hd128"]
+    for batch, ctx in ((1, 700), (3, 300)):
+        eng, w = make_engine(cfg, 21, max_batch=batch, use_graph=False, max_ctx=1024, max_new=12)
+        try:
+            gen = torch.Generator().manual_seed(40 + batch)
+            embs = [torch.randn(ctx - 17 * b, cfg["hidden_size"], generator=gen).half().float() for b in range(batch)]
+            outs = {}
+            for variant in (1, 3, 0):
+                eng.set_option("dec_attn_variant", variant)
+                eng.begin_batch(batch, 12, None)
+                for b in range(batch):
+                    eng.prefill(b, padded(embs[b]), embs[b].shape[0])
+                logits = []
+                for _ in range(6):
+                    eng.decode(1)
+                    logits.append(eng.logits().clone())
+                outs[variant] = (eng.outputs(), torch.stack(logits))
+            assert outs[1][0] == outs[3][0]
+            assert torch.equal(outs[1][1], outs[3][1])
+            assert outs[0][0] == outs[1][0]                  # the un-pipelined kernel: same order too
+        finally:
+            eng.close()

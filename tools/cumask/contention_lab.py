@@ -142,6 +142,23 @@ def main():
         r = pair("dec_attn", sd, fk, sf, alone["dec_attn"], alone[fk])
         print(f"dec_attn    {r['x']:8.1f} us ({r['x'] / alone['dec_attn']:4.2f}x) | {fk:10s} {r['y']:8.1f} us ({r['y'] / alone[fk]:4.2f}x, alone {alone[fk]:.1f}) | clock {r['mhz']:.0f} MHz",
               flush=True)
+    # decode attention variants: 1 (one wave per SIMD, K double-buffered in registers) vs 3 (two waves per SIMD)
+    eng.set_option("gemm_tile_order", 1)
+    for variant in (1, 3):
+        eng.set_option("dec_attn_variant", variant)
+        eng.set_option("gemm_max_wgs", 128)
+        a16 = mb("dec_attn", sd, 400)
+        a_all = mb("dec_attn", free, 400)
+        a20 = mb("dec_attn", cu_masked_stream(20, from_top=True), 400)
+        a12 = mb("dec_attn", cu_masked_stream(12, from_top=True), 400)
+        r = pair("dec_attn", sd, "pre_gateup", sf, a16, galone[0])
+        r2 = pair("dec_attn", sd, "pre_attn", sf, a16, alone["pre_attn"])
+        print(f"dec_attn variant {variant}: alone all CUs {a_all:.1f} us, top 20 / 16 / 12 CUs per XCD {a20:.1f} / {a16:.1f} / {a12:.1f} us | beside gate/up {r['x']:.1f} us "
+              f"(GEMM {r['y']:.1f}) | beside prefill attention {r2['x']:.1f} us (attn {r2['y']:.1f})", flush=True)
+    eng.set_option("dec_attn_variant", 1)
+    if "--attn-only" in sys.argv:
+        eng.close()
+        return
     # tile order of the product GEMM beside the decode attention (0 per-XCD ranges, 1 compact shared blocks, 2 hand-down)
     for fk in ("pre_gateup", "pre_qkv", "pre_down", "pre_o"):
         for order in (0, 1, 2):

@@ -69,7 +69,8 @@ def main():
     F, W, M = (read_pass(os.path.join(root, p)) for p in ("pmc_fetch", "pmc_write", "pmc_mfma"))
     ours = lambda k: k and not (k.startswith("void at::") or "rocprim" in k or k.startswith("__amd_rocclr") or "hipcub" in k)
     keys = sorted({k for k in list(F) + list(W) + list(M) if ours(k[0])})
-    res = {"_note": "per (kernel, grid): means over the dispatches of `bench.py --steps 1 --warmup 0 --max_new_tokens 6 --no-graph` under three "
+    res = {"_note": "per (kernel, grid): means over the dispatches of `bench.py --batch B --prefill-group 4 --batch-mode --steps 1 --warmup 0 --max_new_tokens 6 --no-graph` "
+                    "(B x 2145 = _batch_x_ctx: the decode attention's sequences x cached tokens in this pass) under three "
                     "separate rocprofv3 --pmc passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH half-count correction); "
                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration",
            "_batch_x_ctx": batch_x_ctx, "kernels": []}

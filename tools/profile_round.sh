@@ -5,7 +5,7 @@
 #   2. three SEPARATE --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA busy + GRBM_GUI_ACTIVE) of a short eager step (6 new tokens),
 #      each with --kernel-trace only (gpurun refuses --pmc together with the other trace domains).
 # Summaries land in gpurun_out/prof_<tag>/ and are copied to profiles/ by the builder.
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"
@@ -20,13 +20,14 @@ done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
 fi
-# counters serialise every dispatch: 64 clips keep the three passes at a few minutes (per-launch shapes of the front end are
-# those of the default run - prefill groups of 8, ViT chunks of 16 -; the decode kernels are profiled at 64 rows)
-SHORT="$BENCH --batch 64 --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --batch-mode"
+# counters serialise every dispatch.  Round 3: the pass runs at the DEFAULT batch (128 slots) with the default schedule's prefill groups
+# of 4 clips, so that every kernel is counted at the launch shape the bench line quotes it at (decode kernels at 128 rows and a context
+# of 2142 + <= 5 tokens; prefill GEMMs at M = 4 x 2144) - VERDICT r2: round 2 scaled a 64-row pass and quoted an M = 17152 GEMM
+SHORT="$BENCH --batch ${PMC_BATCH:-128} --prefill-group 4 --steps 1 --warmup 0 --max_new_tokens 6 --no-graph --no-instrument --batch-mode"
 timeout 1500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $SHORT > "$OUT/pmc_fetch.log" 2>&1
 timeout 1500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $SHORT > "$OUT/pmc_write.log" 2>&1
 timeout 1500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- $SHORT > "$OUT/pmc_mfma.log" 2>&1
-python "$REPO/tools/pmc_summary.py" "$OUT" "$OUT/${TAG}_pmc.json" > "$OUT/${TAG}_pmc_summary.txt" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT" "$OUT/${TAG}_pmc.json" $(( ${PMC_BATCH:-128} * 2145 )) > "$OUT/${TAG}_pmc_summary.txt" 2>&1
 # keep the merge-back under 64 MiB: drop the raw per-dispatch csv / db files, keep logs + summaries
 for f in $(find "$OUT" -name "*counter_collection.csv" | head -3); do head -3 "$f" > "$f.head.txt"; done
 find "$OUT" -name "*.csv" -size +2M -delete
