@@ -74,6 +74,7 @@ struct AttnArgs {
     half_t* O;              // [nseq*rows_per_seq, ldo] row-major, head h at columns h*hd
     int ldo;
     int hd;
+    int nqb;                // filled by launch_attention: query blocks of 128 rows per sequence
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
