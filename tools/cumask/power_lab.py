@@ -69,6 +69,16 @@ def main():
         print(f"{label:60s} us: " + ", ".join(f"{k} {v:.1f}" for k, v in box.items()) + " | smi (W, sclk, mclk, fclk): " + " ".join(str(s) for s in samples), flush=True)
 
     eng.set_option("gemm_max_wgs", 128)
+    if "--attn-flavors" in sys.argv:                       # energy of the KV stream by load policy / occupancy (same bytes, same kernel body)
+        for variant, name in ((1, "nt loads, 1 wave/SIMD (product)"), (2, "default-policy loads"), (3, "nt loads, 2 waves/SIMD"), (0, "un-pipelined")):
+            eng.set_option("dec_attn_variant", variant)
+            run([("dec_attn", sd, 4000)], f"decode attention [{name}] on the top 16 CUs per XCD")
+            run([("dec_attn", sa, 4000)], f"decode attention [{name}] on ALL CUs")
+        eng.set_option("dec_attn_variant", 1)
+        for k in ("dec_qkv", "dec_gateup", "dec_down", "dec_o"):
+            run([(k, sa, 40000)], f"{k} on ALL CUs")
+        eng.close()
+        return
     run([("dec_attn", sd, 5000)], "decode attention alone, top 16 CUs per XCD")
     for lab, name in ((0, "product"), (5, "no operand DMA")):
         eng.set_option("gemm_lab", lab)
