@@ -207,6 +207,44 @@ def cpu_baseline(cfg, args, n_kept):
                           "vision_s": c1["vision_s"], "prefill_s": c1["prefill_s"], "s_per_token": c1["s_per_token"]})
 
 
+class PowerSampler:
+    """Socket power and shader clock of this rank's GPU during the timed region (`rocm-smi`, one sample per ~1.5 s from a helper
+    thread; rank 0 only).  Round 3 found the overlapped schedule running AT the 1400 W socket cap with sclk ~2.1 GHz:
+    the line carries the evidence.  Any failure (no rocm-smi, unknown json keys) just leaves the fields out."""
+
+    def __init__(self, card: int):
+        import threading
+        self.card, self.samples, self._stop = card, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.card), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+                card = next(iter(json.loads(out).values()))
+                pw = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
+                sclk = next((float(str(v).strip("()").lower().replace("mhz", "")) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+                if pw is not None and sclk is not None and sclk > 200:
+                    self.samples.append((pw, sclk))
+            except Exception:                                      # noqa: BLE001
+                return
+            self._stop.wait(1.5)
+
+    def start(self):
+        self._t.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._t.join(timeout=30)
+        if not self.samples:
+            return None
+        pw, ck = sorted(p for p, _ in self.samples), sorted(c for _, c in self.samples)
+        return {"socket_power_w_p50": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "sclk_mhz_p50": ck[len(ck) // 2], "sclk_mhz_min": ck[0],
+                "samples": len(pw), "how": "rocm-smi --showpower --showclocks sampled every ~1.5 s during the timed steps"}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no torchrun environment: re-exec this command line as N ranks of ONE node under
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), exactly the launch the driver uses.  Rank 0's
@@ -305,6 +343,7 @@ def main():
     torch.cuda.synchronize()
     ttft_ms = []
     host_ttft, submit_ttft = [], []
+    power = None
 
     def front(bank, record_ttft=False):
         """ViT + projector/splice + prefill of one batch into generation bank `bank` (enqueue only)."""
@@ -557,6 +596,7 @@ def main():
         for _ in range(max(args.warmup - 1, 1 if overlap else 0)):  # overlap: the first front end above overlapped nothing
             cycle(False, False)
         fence()
+        sampler = PowerSampler(local).start() if rank == 0 else None
         t_start = time.perf_counter()
         outs = []
         for _ in range(args.steps):
@@ -564,6 +604,7 @@ def main():
             outs.append(out)
         fence()
         elapsed = time.perf_counter() - t_start
+        power = sampler.stop() if sampler else None
         # same clips in the same slots as the batch-mode step: batch-invariant kernels must give the same ids, every cycle
         assert all(o == batch_ref for o in outs), "continuous batching produced different captions than the batch-mode step"
         if overlap and args.gemm_cus <= 0:
@@ -580,6 +621,7 @@ def main():
         for _ in range(args.warmup):
             step()
         fence()
+        sampler = PowerSampler(local).start() if rank == 0 else None
         t_start = time.perf_counter()
         outs = []
         for _ in range(args.steps):
@@ -587,6 +629,7 @@ def main():
             outs.append(out)
         fence()
         elapsed = time.perf_counter() - t_start
+        power = sampler.stop() if sampler else None
         # every step captions the same synthetic clips: the ids must repeat exactly (a race or a stale buffer would show)
         assert all(o == outs[0] for o in outs), "generated ids differ between identical steps"
     else:
@@ -687,6 +730,7 @@ def main():
                                    % (fc, k_masked, 32 - fc) if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
+            "power": power,
             "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
             "ttft_host_note": ("host clock from the moment a group's front end STARTS on the device (a helper thread waits for its first event) to its "
                                "first token ids sitting in pinned host memory (a side stream copies them after the commit; a second helper thread "
