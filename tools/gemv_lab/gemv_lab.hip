@@ -646,6 +646,19 @@ static void lab(int iters, const char* only) {
             run("skx T4 KS3 S4 reg R2 NL2 + reduce", [&](int cp) { launch_skx<4, 3, KCR, 3, 2, 0, (NB <= 4 ? 2 : 3), NB, 1>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
             run("skx T4 KS3 S4 reg R3 NL4 KC6 + reduce", [&](int cp) { launch_skx<4, 3, 6, 4, 2, 0, 4, NB, 1>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
             run("skx T8 KS1 S8 dma NL4 + reduce", [&](int cp) { launch_skx<8, 1, 4, 4, 4, 0, 4, NB, 0>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); red(8); }, true, 0);
+            if constexpr (NB > 4) {       // round 3: is the shipped geometry (a barrier per k32 step: KC 3 / KS 3) the best one for the residual projections?
+                run("skx T4 KS3 S4 main only (shipped)", [&](int cp) { launch_skx<4, 3, KCR, NBUFR, 2, 0, NLR, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); }, false, 0);
+                run("skx T4 KS2 KC8 NBUF2 U4 NL4 S4 + reduce", [&](int cp) { launch_skx<4, 2, 8, 2, 4, 0, 4, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+                run("skx T4 KS2 KC8 NBUF2 U2 NL4 S4 + reduce", [&](int cp) { launch_skx<4, 2, 8, 2, 2, 0, 4, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+                run("skx T4 KS2 KC4 NBUF4 U4 NL4 S4 + reduce", [&](int cp) { launch_skx<4, 2, 4, 4, 4, 0, 4, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+                run("skx T4 KS3 KC6 NBUF2 U2 NL3 S4 + reduce", [&](int cp) { launch_skx<4, 3, 6, 2, 2, 0, 3, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+                run("skx T4 KS3 KC6 NBUF2 U4 NL3 S4 + reduce", [&](int cp) { launch_skx<4, 3, 6, 2, 4, 0, 3, NB, 0>(dim3(sh.N16 / 4, 4), mk(cp, part, 4, 4, 0), st); red(4); }, true, 0);
+                run("skx T2 KS4 KC8 NBUF2 U2 NL4 S2 + reduce", [&](int cp) { launch_skx<2, 4, 8, 2, 2, 0, 4, NB, 0>(dim3(sh.N16 / 2, 2), mk(cp, part, 2, 2, 0), st); red(2); }, true, 0);
+                run("skx T2 KS4 KC8 NBUF2 U4 NL4 S2 + reduce", [&](int cp) { launch_skx<2, 4, 8, 2, 4, 0, 4, NB, 0>(dim3(sh.N16 / 2, 2), mk(cp, part, 2, 2, 0), st); red(2); }, true, 0);
+                run("skx T2 KS6 KC6 NBUF2 U1 NL4 S2 + reduce", [&](int cp) { launch_skx<2, 6, 6, 2, 1, 0, 4, NB, 0>(dim3(sh.N16 / 2, 2), mk(cp, part, 2, 2, 0), st); red(2); }, true, 0);
+                run("skx T8 KS1 KC8 NBUF2 U8 NL4 S8 + reduce", [&](int cp) { launch_skx<8, 1, 8, 2, 8, 0, 4, NB, 0>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); red(8); }, true, 0);
+                run("skx T8 KS1 KC8 NBUF2 U8 NL4 S8 main only", [&](int cp) { launch_skx<8, 1, 8, 2, 8, 0, 4, NB, 0>(dim3(sh.N16 / 8, 8), mk(cp, part, 8, 8, 0), st); }, false, 0);
+            }
             if constexpr (NB <= 4) run("skx T1 KS8 S1 dma NL8", [&](int cp) { launch_skx<1, 8, 8, 4, 4, 0, 8, NB, 0>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
             if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL4", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 4, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
             if constexpr (NB <= 4) run("skx T1 KS8 S1 reg R2 NL8", [&](int cp) { launch_skx<1, 8, 8, 3, 4, 0, 8, NB, 1>(dim3(sh.N16, 1), mk(cp, out, 1, 1, 0), st); }, true, 0);
