@@ -1171,6 +1171,144 @@ __global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a)
     }
 }
 
+// Variant 4: the same page pipeline on the VALU (v_dot2c_f32_f16) instead of the matrix cores.  One query per (sequence, head) makes the
+// decode attention a GEMV: the MFMA forms above replicate q over the 16 columns of a 16x16x32 tile and throw 15 / 16 of every
+// product away - 32 MFMAs = 524 k MACs per 32 KiB page for 16 k useful ones.  Measured (tools/cumask/power_lab.py): the kernel draws
+// 1200 W at 7.3 TB/s where a bare read stream of the same rate draws ~1000 W, and the serving schedule runs AT the 1400 W socket cap
+// (DESIGN section 4): those watts are throughput.  Here a lane keeps the layout the fragments give it - lane (g, r) holds token
+// kt * 16 + r x the 8 PAIRED dims of group g of a K fragment, feature d16 * 16 + r x the 8 PAIRED tokens of group g of a V^T fragment:
+//   Q K^T : 4 v_dot2c per fragment into ONE fp32 per (lane, kt); the 4 dim groups of a token meet by two row exchanges (xor 16, 32)
+//   softmax: 4 scores per lane instead of 16 (the MFMA accumulators held every score four times over)
+//   P     : 64 probabilities -> LDS as fp16 in token order (lane l writes token l), read back as the PAIRED token groups of the V^T
+//           fragments (two 8-byte reads per 32 tokens): 128 B of LDS per wave, same wave writes and reads - no barrier
+//   P V   : 4 v_dot2c per fragment into one fp32 per (lane, d16); the 4 token groups meet once, after the last page
+// 128 dot products + ~40 other VALU operations per page instead of 32 MFMAs + ~250; registers as variant 3 (two waves per SIMD).
+// Different summation order than variants 0 / 1 / 3 (not bitwise equal to them); deterministic and batch-invariant like them.
+__device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
+    c = __builtin_amdgcn_fdot2(h2{a[0], a[1]}, h2{b[0], b[1]}, c, false);
+    c = __builtin_amdgcn_fdot2(h2{a[2], a[3]}, h2{b[2], b[3]}, c, false);
+    c = __builtin_amdgcn_fdot2(h2{a[4], a[5]}, h2{b[4], b[5]}, c, false);
+    c = __builtin_amdgcn_fdot2(h2{a[6], a[7]}, h2{b[6], b[7]}, c, false);
+    return c;
+}
+template <int KBLK, int VD16>
+__global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) half_t p16[64];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, r = lane & 15;
+    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const KvLayout& kv = a.kv;
+    const int npos = a.pos[b] + 1;
+    const int seq = a.seq_ids ? a.seq_ids[b] : b;
+    const int npages = (npos + 63) >> 6;
+    const int p_first = sp * a.pages_per_split;
+    int p_last = p_first + a.pages_per_split;
+    p_last = p_last < npages ? p_last : npages;
+    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
+
+    h8 qf[KBLK];
+#pragma unroll
+    for (int blk = 0; blk < KBLK; ++blk)
+        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
+    float acc_o[VD16];                                   // feature d16 * 16 + r, summed over this lane's token group so far
+#pragma unroll
+    for (int d = 0; d < VD16; ++d) acc_o[d] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                // l_run: this lane's tokens (r, 16 + r, 32 + r, 48 + r of every page)
+    const float sc = a.scale * 1.4426950408889634f;
+    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;
+    const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;
+
+    h8 kf[4 * KBLK];
+    if (p_first < p_last) {
+        const half_t* page = kv_page(kv, seq, p_first * 64);
+#pragma unroll
+        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
+    }
+    for (int p = p_first; p < p_last; ++p) {
+        const half_t* page = kv_page(kv, seq, p * 64);
+        h8 vf[VD16 * 2];
+#pragma unroll
+        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
+        const bool more = p + 1 < p_last;                 // wave-uniform
+        const int key0 = p * 64;
+        float s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            float part = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < KBLK; ++blk) part = dot8(kf[kt * KBLK + blk], qf[blk], part);
+            s[kt] = part;
+        }
+        if (more) {                                       // K of the next page into the registers the products above have just read
+            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            float v = s[kt];
+            v += __shfl_xor(v, 16, 64);                   // the 4 dim groups of token kt * 16 + r: every one of its 4 lanes gets the same bits
+            v += __shfl_xor(v, 32, 64);
+            v = (key0 + kt * 16 + r) < npos ? v * sc : -INFINITY;
+            s[kt] = v;
+            mx = fmaxf(mx, v);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));      // over the 16 token lanes (the 4 groups already agree)
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float ps = 0.f, mine = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float pv = __builtin_amdgcn_exp2f(s[kt] - m_new);
+            ps += pv;
+            mine = kt == g ? pv : mine;                   // lane l = g * 16 + r publishes token l of the page
+        }
+        l_run = l_run * alpha + ps;
+        p16[lane] = (half_t)mine;
+        h8 pf[2];
+#pragma unroll
+        for (int b32 = 0; b32 < 2; ++b32) {               // PAIRED token order of a V^T fragment: tokens 4g .. 4g + 3 and 16 + 4g .. of the 32
+            const h4 lo = *(const h4*)(p16 + b32 * 32 + 4 * g);
+            const h4 hi = *(const h4*)(p16 + b32 * 32 + 16 + 4 * g);
+            pf[b32] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) {
+            float o = acc_o[d] * alpha;
+            o = dot8(vf[d * 2 + 0], pf[0], o);
+            o = dot8(vf[d * 2 + 1], pf[1], o);
+            acc_o[d] = o;
+        }
+    }
+    float l = l_run;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) l += __shfl_xor(l, o, 64);       // over the token lanes; the 4 groups hold the same sum
+#pragma unroll
+    for (int d = 0; d < VD16; ++d) {                      // the 4 token groups of a feature
+        acc_o[d] += __shfl_xor(acc_o[d], 16, 64);
+        acc_o[d] += __shfl_xor(acc_o[d], 32, 64);
+    }
+    if (a.nsplit == 1) {
+#pragma unroll
+        for (int d = 0; d < VD16; ++d) {
+            if ((d & 3) != g) continue;                   // every lane stores its share: features d16 = g, g + 4
+            const int k = head * a.hd + d * 16 + r;
+            a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(acc_o[d] / l);
+        }
+        return;
+    }
+#pragma unroll
+    for (int d = 0; d < VD16; ++d)
+        if ((d & 3) == g) a.part_o[pidx * a.hd + d * 16 + r] = acc_o[d];
+    if (lane == 0) {
+        a.part_ml[pidx * 2 + 0] = m_run;
+        a.part_ml[pidx * 2 + 1] = l;
+    }
+}
+
 __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     if (d >= a.hd) return;
@@ -1195,6 +1333,9 @@ hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     const bool pipe = a.variant >= 1 && a.kv.page_tokens == 64;
     if (a.variant == 2 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8, false>), grid, dim3(64), 0, s, a);
     else if (a.variant == 3 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe2_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    else if (a.variant == 4 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    else if (a.variant == 4 && pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_dot_kernel<1, 2>), grid, dim3(64), 0, s, a);
+    else if (a.variant == 4 && pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_dot_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_pipe_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_pipe_kernel<1, 2>), grid, dim3(64), 0, s, a);

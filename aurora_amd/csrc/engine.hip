@@ -71,7 +71,7 @@ struct aur_ctx {
     int32_t* ptab_rw() { return const_cast<int32_t*>(ptab_cur); }
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
-    int attn_variant = 1, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option)
+    int attn_variant = 4, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option); decode attention: 4 = VALU dot products (decode.hip)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)

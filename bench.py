@@ -95,6 +95,7 @@ def parse():
     p.add_argument("--gemm-tail-split", type=int, default=-1, help="A/B: 0 = one 256x256 launch per GEMM, 1 = idle last rounds go to the 128x128 kernel")
     p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
+    p.add_argument("--dec-attn-variant", type=int, default=-1, help="A/B: decode attention kernel (1 MFMA page pipeline, 3 the same with two waves per SIMD, 4 VALU dot products)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
@@ -332,6 +333,8 @@ def main():
         eng.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.gemm_tail_split >= 0:
         eng.set_option("gemm_tail_split", args.gemm_tail_split)
+    if args.dec_attn_variant >= 0:
+        eng.set_option("dec_attn_variant", args.dec_attn_variant)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B
@@ -792,10 +795,11 @@ def main():
             mean_ctx = L0 + N / 2.0
             alg = B * mean_ctx * 2 * d * 2                               # K + V bytes (q and the split partials are < 0.1 %)
             avg_s = ams / an * 1e-3
-            roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_pipe_kernel<4, 8> (paged decode attention)",
+            att_pmc = pmc_of("decode_attn_dot_kernel") or pmc_of("decode_attn_pipe_kernel")
+            roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_dot_kernel<4, 8> (paged decode attention, v_dot2c page pipeline)" if args.dec_attn_variant in (-1, 4)
+                                   else "decode_attn_pipe_kernel<4, 8> (paged decode attention, MFMA page pipeline)",
                                    "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                   "traffic": (pmc_of("decode_attn_pipe_kernel")["hbm_bytes_per_launch"] * (B * mean_ctx) / pmc_ctx)
-                                   if (pmc_of("decode_attn_pipe_kernel") and pmc_ctx) else None,
+                                   "traffic": (att_pmc["hbm_bytes_per_launch"] * (B * mean_ctx) / pmc_ctx) if (att_pmc and pmc_ctx) else None,
                                    "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/%s_pmc.json (separate passes of this command at "
                                                    "the same batch and 6 new tokens), scaled by (this run's mean context) / (the pass's context) = %.3f"
                                                    % (pmc_tag, (B * mean_ctx) / pmc_ctx if pmc_ctx else float("nan")),

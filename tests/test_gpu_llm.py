@@ -292,3 +292,56 @@ def test_decode_attention_variants_are_bitwise_equal():
             assert outs[0][0] == outs[1][0]                  # the un-pipelined kernel: same order too
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("name", ["hd32", "hd128"])
+def test_decode_attention_on_the_valu_matches_the_mfma_form(name):
+    """dec_attn_variant 4 computes the decode attention with v_dot2c_f32_f16 instead of MFMAs whose 16 columns all hold the same
+    query (15 / 16 of the products wasted - watts, on a path that runs at the socket power cap).  Different summation order, so
+    not bitwise the MFMA form: logits within 2e-3 of the logit scale of variant 1 and within the kernel tolerance of the fp32
+    oracle, tokens equal wherever the oracle's margin is clear; deterministic; batched == single; graph == eager."""
+    cfg = LLM_CFGS[name]
+    ref = {}
+    for batch, ctx in ((1, 700), (3, 300)):
+        eng, w = make_engine(cfg, 21, max_batch=batch, use_graph=False, max_ctx=1024, max_new=12)
+        try:
+            gen = torch.Generator().manual_seed(40 + batch)
+            embs = [torch.randn(ctx - 17 * b, cfg["hidden_size"], generator=gen).half().float() for b in range(batch)]
+            outs = {}
+            for variant in (1, 4, 4):
+                eng.set_option("dec_attn_variant", variant)
+                eng.begin_batch(batch, 12, None)
+                for b in range(batch):
+                    eng.prefill(b, padded(embs[b]), embs[b].shape[0])
+                logits = []
+                for _ in range(6):
+                    eng.decode(1)
+                    logits.append(eng.logits().clone())
+                cur = (eng.outputs(), torch.stack(logits))
+                if variant in outs:                          # second run of variant 4: bitwise repeatable
+                    assert cur[0] == outs[variant][0] and torch.equal(cur[1], outs[variant][1])
+                outs[variant] = cur
+            scale = outs[1][1].abs().max().item()
+            assert (outs[1][1] - outs[4][1]).abs().max().item() <= 2e-3 * scale
+            # against the oracle: teacher-forced logits of the tokens variant 4 produced, slot 0
+            ids = outs[4][0][0]
+            want = teacher_forced_logits(embs[0], ids[:7], w, cfg)
+            got = outs[4][1][:, 0].float().cpu()
+            assert (got - want[1:7]).abs().max().item() <= LOGIT_TOL * want.abs().max().item()
+            ref[batch] = (embs, outs[4])
+        finally:
+            eng.close()
+    # graph replay == eager launches, and a batch == its sequences alone, with the VALU form
+    eng, w = make_engine(cfg, 21, max_batch=3, use_graph=True, max_ctx=1024, max_new=12)
+    try:
+        eng.set_option("dec_attn_variant", 4)
+        embs, (ids3, _) = ref[3]
+        eng.begin_batch(3, 12, None)
+        for b in range(3):
+            eng.prefill(b, padded(embs[b]), embs[b].shape[0])
+        eng.decode(6)
+        assert eng.outputs() == ids3
+        for b in range(3):
+            assert eng.generate([padded(embs[b])], [embs[b].shape[0]], 7, eos_id=None)[0] == ids3[b]
+    finally:
+        eng.close()

@@ -144,7 +144,7 @@ def main():
               flush=True)
     # decode attention variants: 1 (one wave per SIMD, K double-buffered in registers) vs 3 (two waves per SIMD)
     eng.set_option("gemm_tile_order", 1)
-    for variant in (1, 3):
+    for variant in (1, 3, 4):
         eng.set_option("dec_attn_variant", variant)
         eng.set_option("gemm_max_wgs", 128)
         a16 = mb("dec_attn", sd, 400)

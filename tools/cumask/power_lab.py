@@ -69,8 +69,32 @@ def main():
         print(f"{label:60s} us: " + ", ".join(f"{k} {v:.1f}" for k, v in box.items()) + " | smi (W, sclk, mclk, fclk): " + " ".join(str(s) for s in samples), flush=True)
 
     eng.set_option("gemm_max_wgs", 128)
+    if "--stream" in sys.argv:                             # a bare HBM read stream (no MFMA, one add per 16 bytes) beside the decode attention's watts
+        import ctypes as C
+        from tools.cumask.contention_lab import clock_probe_lib
+        lib = clock_probe_lib()
+        lib.lab_stream_launch.restype = C.c_int
+        lib.lab_stream_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        big = torch.zeros(8 << 30, dtype=torch.uint8, device="cuda")
+        sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+        for st, name, blocks in ((sa, "ALL CUs", 2048), (sa, "ALL CUs", 1024), (sd, "top 16 CUs per XCD", 1024)):
+            samples = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(st):
+                e0.record()
+                lib.lab_stream_launch(C.c_void_p(st.cuda_stream), C.c_void_p(big.data_ptr()), 8 << 30, 2500, blocks, 1, C.c_void_p(sink.data_ptr()))
+                e1.record()
+            time.sleep(0.5)
+            for _ in range(4):
+                samples.append(smi())
+                time.sleep(0.3)
+            e1.synchronize()
+            print(f"bare nt read stream on {name} ({blocks} wgs): {(8 << 30) * 2500 / (e0.elapsed_time(e1) * 1e-3) / 1e12:.2f} TB/s | smi: " + " ".join(str(x) for x in samples), flush=True)
+        run([("dec_attn", sa, 4000)], "decode attention on ALL CUs")
+        eng.close()
+        return
     if "--attn-flavors" in sys.argv:                       # energy of the KV stream by load policy / occupancy (same bytes, same kernel body)
-        for variant, name in ((1, "nt loads, 1 wave/SIMD (product)"), (2, "default-policy loads"), (3, "nt loads, 2 waves/SIMD"), (0, "un-pipelined")):
+        for variant, name in ((1, "MFMA, nt loads, 1 wave/SIMD"), (4, "VALU dot2c, 2 waves/SIMD"), (2, "MFMA, default-policy loads"), (3, "MFMA, nt loads, 2 waves/SIMD"), (0, "MFMA, un-pipelined")):
             eng.set_option("dec_attn_variant", variant)
             run([("dec_attn", sd, 4000)], f"decode attention [{name}] on the top 16 CUs per XCD")
             run([("dec_attn", sa, 4000)], f"decode attention [{name}] on ALL CUs")
