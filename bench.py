@@ -96,6 +96,8 @@ def parse():
     p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--dec-attn-variant", type=int, default=-1, help="A/B: decode attention kernel (1 MFMA page pipeline, 3 the same with two waves per SIMD, 4 VALU dot products)")
+    p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "
+                                                          "skipped automatically under rocprofv3, whose launch interception does not survive the fork)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-instrument", action="store_true", help="skip the event-bracketed roofline pass")
@@ -347,6 +349,7 @@ def main():
     ttft_ms = []
     host_ttft, submit_ttft = [], []
     power = None
+    want_power = not args.no_power and not any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
 
     def front(bank, record_ttft=False):
         """ViT + projector/splice + prefill of one batch into generation bank `bank` (enqueue only)."""
@@ -599,7 +602,7 @@ def main():
         for _ in range(max(args.warmup - 1, 1 if overlap else 0)):  # overlap: the first front end above overlapped nothing
             cycle(False, False)
         fence()
-        sampler = PowerSampler(local).start() if rank == 0 else None
+        sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None
         t_start = time.perf_counter()
         outs = []
         for _ in range(args.steps):
@@ -624,7 +627,7 @@ def main():
         for _ in range(args.warmup):
             step()
         fence()
-        sampler = PowerSampler(local).start() if rank == 0 else None
+        sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None
         t_start = time.perf_counter()
         outs = []
         for _ in range(args.steps):

@@ -81,3 +81,31 @@ extern "C" int lab_share_launch(void* stream, const void* p, int64_t bytes, int6
     hipLaunchKernelGGL(lab_share_kernel, dim3(blocks & ~7), dim3(256), 0, (hipStream_t)stream, (const f4v*)p, bytes / 16, stagger_bytes / 16, sink);
     return (int)hipGetLastError();
 }
+
+// ---- the decode attention's ADDRESS pattern without its arithmetic: one wave per (slot, head) walks the slot's pages (1 MiB each, all
+// heads of 64 tokens) and reads its head's 16 KiB of K fragments and, 512 KiB further, its 16 KiB of V^T fragments - 32 non-temporal
+// 1 KiB loads per page, summed into one register.  mode 1 = the same bytes with the heads interleaved at fragment granularity
+// ([fragment][head] instead of [head][fragment]): the 32 waves of a slot, which run in near lock-step, then touch one contiguous 32 KiB
+// per fragment index instead of 32 pieces 16 KiB apart.  Is the ~25 pJ/B between the decode attention and a bare stream DRAM row locality?
+__global__ __launch_bounds__(64) void lab_kvpattern_kernel(const f4v* __restrict__ pool, int pages_per_slot, int mode, float* sink) {
+    const int head = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < pages_per_slot; ++p) {
+        const f4v* page = pool + ((int64_t)slot * pages_per_slot + p) * 65536;            // 1 MiB = 65536 x 16 B
+        f4v v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int part = i >> 4, f = i & 15;                                              // K part / V part, fragment
+            const int64_t off = mode == 0 ? (int64_t)part * 32768 + head * 1024 + f * 64      // [part][head][fragment][lane]
+                                          : (int64_t)part * 32768 + f * 2048 + head * 64;      // [part][fragment][head][lane]
+            v[i] = __builtin_nontemporal_load(page + off + lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += v[i];
+    }
+    if (acc.x == 1.2345f) sink[0] = acc.y + acc.z + acc.w;
+}
+extern "C" int lab_kvpattern_launch(void* stream, const void* pool, int slots, int pages_per_slot, int mode, float* sink) {
+    hipLaunchKernelGGL(lab_kvpattern_kernel, dim3(1, 32, slots), dim3(64), 0, (hipStream_t)stream, (const f4v*)pool, pages_per_slot, mode, sink);
+    return (int)hipGetLastError();
+}

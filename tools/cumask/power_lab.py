@@ -91,6 +91,26 @@ def main():
             e1.synchronize()
             print(f"bare nt read stream on {name} ({blocks} wgs): {(8 << 30) * 2500 / (e0.elapsed_time(e1) * 1e-3) / 1e12:.2f} TB/s | smi: " + " ".join(str(x) for x in samples), flush=True)
         run([("dec_attn", sa, 4000)], "decode attention on ALL CUs")
+        # the attention's address pattern without its arithmetic, in the pool's layout and with heads interleaved per fragment
+        lib.lab_kvpattern_launch.restype = C.c_int
+        lib.lab_kvpattern_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        for mode, name in ((0, "[head][fragment] (the KV pool's layout)"), (1, "[fragment][head]")):
+            samples = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps, slots, pps = 400, 128, 36
+            with torch.cuda.stream(sa):
+                e0.record()
+                for _ in range(reps):
+                    lib.lab_kvpattern_launch(C.c_void_p(sa.cuda_stream), C.c_void_p(big.data_ptr()), slots, pps, mode, C.c_void_p(sink.data_ptr()))
+                e1.record()
+            time.sleep(0.5)
+            for _ in range(4):
+                samples.append(smi())
+                time.sleep(0.3)
+            e1.synchronize()
+            nbytes = reps * slots * pps * (1 << 20)
+            print(f"KV address pattern {name}: {nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12:.2f} TB/s ({e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch) | smi: "
+                  + " ".join(str(x) for x in samples), flush=True)
         eng.close()
         return
     if "--attn-flavors" in sys.argv:                       # energy of the KV stream by load policy / occupancy (same bytes, same kernel body)

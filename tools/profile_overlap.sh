@@ -7,7 +7,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for attempt in 1 2 3; do
   rm -rf "$OUT/trace"
-  timeout 1200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o ovl -- python $REPO/bench.py --no-cpu-baseline --no-instrument --steps 1 --warmup 1 --sync-chunks > "$OUT/trace.log" 2>&1 && break
+  timeout 1200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o ovl -- python $REPO/bench.py --no-cpu-baseline --no-power --no-instrument --steps 1 --warmup 1 --sync-chunks > "$OUT/trace.log" 2>&1 && break
 done
 python $REPO/tools/overlap_trace_summary.py "$OUT/trace" "$OUT/${TAG}_overlap_trace_summary.txt"
 find "$OUT" -name "*.csv" -size +2M -delete

@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-power"
 if [ "$2" != "pmc" ]; then
 for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside a kernel launch: retry
   rm -rf "$OUT/trace"
