@@ -657,13 +657,10 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             gm.S = 4;
             gm.tiles_lo = 4;
             gm.n_hi = 0;
-            // 5-8 column groups (round 3, profiles/r03_gemv_lab_row.log): 2 k phases per tile over chunks of 8 k32 (a barrier per 4 steps of
-            // a wave instead of one per step) - o 18.9 -> 18.0 us, down 31.5 -> 29.4 us incl. the reduce; 27.3 -> 25.3 and 47.6 -> 45.3 us on
-            // 16 CUs per XCD.  A constant of the engine's capacity like every other geometry here: the summation order never depends
-            // on the live batch.
-            hipError_t e;
-            if constexpr (NB > 4) e = launch_skx_t<4, 2, SK_ROW, NB, 8, 2, 4, 4>(a, gm, dim3(N16 / 4, 4), s);
-            else e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
+            // (round 3 re-swept this geometry in tools/gemv_lab, profiles/r03_gemv_lab_row.log: 2 k phases over chunks of 8 k32 is 1-2 us faster
+            // there, o 18.9 -> 18.0 us, down 31.5 -> 29.4 us incl. the reduce, but neutral in the engine - 19.3 / 30.1 us either way - and
+            // rocprofv3's counter mode crashed in this launch with that instantiation: kept as it was)
+            hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);
             return hipGetLastError();

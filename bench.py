@@ -96,6 +96,8 @@ def parse():
     p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--dec-attn-variant", type=int, default=-1, help="A/B: decode attention kernel (1 MFMA page pipeline, 3 the same with two waves per SIMD, 4 VALU dot products)")
+    p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
+                                                            "launches short - rocprofv3's counter mode crashed with ~11 k launches queued ahead of the GPU)")
     p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "
                                                           "skipped automatically under rocprofv3, whose launch interception does not survive the fork)")
     p.add_argument("--no-graph", action="store_true")
@@ -368,6 +370,8 @@ def main():
                 _, L = eng.project_splice(vis[(b0 - v0 + j) * F:(b0 - v0 + j + 1) * F], plan=plans[b0 + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
                 assert L == L0
             eng.prefill_batch(b0, n, emb_all, L0)
+            if args.sync_front:
+                torch.cuda.current_stream().synchronize()
             if record_ttft:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
