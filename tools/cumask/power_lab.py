@@ -97,7 +97,7 @@ def main():
         for mode, name in ((0, "[head][fragment] (the KV pool's layout)"), (1, "[fragment][head]")):
             samples = []
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps, slots, pps = 400, 128, 36
+            reps, slots, pps = 5000, 128, 36
             with torch.cuda.stream(sa):
                 e0.record()
                 for _ in range(reps):
