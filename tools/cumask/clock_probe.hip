@@ -109,3 +109,90 @@ extern "C" int lab_kvpattern_launch(void* stream, const void* pool, int slots, i
     hipLaunchKernelGGL(lab_kvpattern_kernel, dim3(1, 32, slots), dim3(64), 0, (hipStream_t)stream, (const f4v*)pool, pages_per_slot, mode, sink);
     return (int)hipGetLastError();
 }
+
+// ---- the KV walk with the attention's arithmetic added piece by piece (work bits): 1 = 128 v_dot2c per page against a register-resident
+// vector (the Q K^T and P V products), 2 = the cross-lane traffic of the softmax (8 + 4 + 4 ds_bpermute-class exchanges per page), 4 = 5 v_exp +
+// the probability exchange through 128 B of LDS.  Which piece carries the ~200 W between a bare KV walk and the decode attention?
+typedef _Float16 lh2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lh8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float lab_dot8(const lh8 a, const lh8 b, float c) {
+    c = __builtin_amdgcn_fdot2(lh2{a[0], a[1]}, lh2{b[0], b[1]}, c, false);
+    c = __builtin_amdgcn_fdot2(lh2{a[2], a[3]}, lh2{b[2], b[3]}, c, false);
+    c = __builtin_amdgcn_fdot2(lh2{a[4], a[5]}, lh2{b[4], b[5]}, c, false);
+    c = __builtin_amdgcn_fdot2(lh2{a[6], a[7]}, lh2{b[6], b[7]}, c, false);
+    return c;
+}
+__global__ __launch_bounds__(64, 2) void lab_kvwork_kernel(const lh8* __restrict__ pool, int pages_per_slot, int work, float* sink) {
+    __shared__ _Float16 p16[64];
+    const int head = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
+    lh8 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = pool[lane + i * 64];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m = 0.f;
+    for (int p = 0; p < pages_per_slot; ++p) {
+        const lh8* page = pool + ((int64_t)slot * pages_per_slot + p) * 65536;
+        lh8 v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = __builtin_nontemporal_load(page + (int64_t)(i >> 4) * 32768 + head * 1024 + (i & 15) * 64 + lane);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (work & 1) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) s[kt] = lab_dot8(v[kt * 4 + b], q[b], s[kt]);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[kt] = (float)v[kt * 4][0] + (float)v[kt * 4 + 1][1] + (float)v[kt * 4 + 2][2] + (float)v[kt * 4 + 3][3];
+        }
+        if (work & 2) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] += __shfl_xor(s[kt], 16, 64);
+                s[kt] += __shfl_xor(s[kt], 32, 64);
+                mx = fmaxf(mx, s[kt]);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            m = fmaxf(m, mx);
+        }
+        lh8 pf[2];
+        if (work & 4) {
+            float mine = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt] - m);
+                mine = kt == (lane >> 4) ? pv : mine;
+            }
+            p16[lane] = (_Float16)mine;
+            const int g = lane >> 4;
+#pragma unroll
+            for (int b32 = 0; b32 < 2; ++b32) {
+                typedef _Float16 lh4 __attribute__((ext_vector_type(4)));
+                const lh4 lo = *(const lh4*)(p16 + b32 * 32 + 4 * g), hi = *(const lh4*)(p16 + b32 * 32 + 16 + 4 * g);
+                pf[b32] = lh8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        } else {
+            pf[0] = q[0];
+            pf[1] = q[1];
+        }
+        if (work & 1) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                acc[d] = lab_dot8(v[16 + d * 2], pf[0], acc[d] * 0.999f);
+                acc[d] = lab_dot8(v[16 + d * 2 + 1], pf[1], acc[d]);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[d] += (float)v[16 + d * 2][d & 7] + (float)v[16 + d * 2 + 1][d & 7] + s[d & 3];
+        }
+    }
+    float t = m;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) t += acc[d];
+    if (t == 1.2345f) sink[0] = t;
+}
+extern "C" int lab_kvwork_launch(void* stream, const void* pool, int slots, int pages_per_slot, int work, float* sink) {
+    hipLaunchKernelGGL(lab_kvwork_kernel, dim3(1, 32, slots), dim3(64), 0, (hipStream_t)stream, (const lh8*)pool, pages_per_slot, work, sink);
+    return (int)hipGetLastError();
+}

@@ -111,6 +111,26 @@ def main():
             nbytes = reps * slots * pps * (1 << 20)
             print(f"KV address pattern {name}: {nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12:.2f} TB/s ({e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch) | smi: "
                   + " ".join(str(x) for x in samples), flush=True)
+        lib.lab_kvwork_launch.restype = C.c_int
+        lib.lab_kvwork_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        for work, name in ((0, "walk only"), (1, "+ 128 v_dot2c per page"), (3, "+ dot2c + softmax exchanges"), (7, "+ dot2c + exchanges + exp + LDS hand-over (= the attention)"),
+                           (2, "+ exchanges only"), (4, "+ exp + LDS only")):
+            samples = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps, slots, pps = 5000, 128, 36
+            with torch.cuda.stream(sa):
+                e0.record()
+                for _ in range(reps):
+                    lib.lab_kvwork_launch(C.c_void_p(sa.cuda_stream), C.c_void_p(big.data_ptr()), slots, pps, work, C.c_void_p(sink.data_ptr()))
+                e1.record()
+            time.sleep(0.5)
+            for _ in range(4):
+                samples.append(smi())
+                time.sleep(0.3)
+            e1.synchronize()
+            nbytes = reps * slots * pps * (1 << 20)
+            print(f"KV walk {name}: {nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12:.2f} TB/s ({e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch) | W: "
+                  + " ".join(str(x[0]) for x in samples), flush=True)
         eng.close()
         return
     if "--attn-flavors" in sys.argv:                       # energy of the KV stream by load policy / occupancy (same bytes, same kernel body)
