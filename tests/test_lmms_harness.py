@@ -70,7 +70,23 @@ def _import_reference_harness():
     return models, registry, task, evaluator
 
 
-def test_reference_harness_drives_the_adaptor():
+@pytest.fixture
+def clean_process_state():
+    """the harness import leaves traces (sys.path entry, stub modules, LMMS_EVAL_PLUGINS, the plugin re-imported under the real base
+    class): put the process back so that the other test files see what they would have seen without this one"""
+    path, mods, env = list(sys.path), dict(sys.modules), os.environ.get("LMMS_EVAL_PLUGINS")
+    yield
+    sys.path[:] = path
+    for k in [k for k in sys.modules if k not in mods]:
+        del sys.modules[k]
+    sys.modules.update(mods)
+    if env is None:
+        os.environ.pop("LMMS_EVAL_PLUGINS", None)
+    else:
+        os.environ["LMMS_EVAL_PLUGINS"] = env
+
+
+def test_reference_harness_drives_the_adaptor(clean_process_state):
     import datasets
     from tests.test_lmms_plugin import FakeTok, FakeModel, fake_pre
     models, registry, task_mod, evaluator = _import_reference_harness()
