@@ -23,6 +23,13 @@ tower's encoder weights, `hidden_states[-2][:, 1:]` (aurora.py:253), the referen
 `prepare_inputs_labels_for_multimodal` (model/utils.py:138-295) and HF greedy `generate` (inference.py:89-96), fp32 arithmetic on the
 fp16-stored weights.  The full `AuroraEncoder` / `AuroraModel` wrappers cannot run on transformers 5.x; the
 composition above is the call sequence of aurora.py:214-258 made of the pieces that do.
+
+G14 (the CLI path, inference.py:58-98, on the same directory): a real HF tokenizer - a small Llama-style BPE vocabulary (metaspace, `<unk>` /
+`<s>` / `</s>` = 0 / 1 / 2) trained here on a few sentences with the `tokenizers` library and written by `PreTrainedTokenizerFast.save_pretrained`
+(`tokenizer.json`, `tokenizer_config.json`; no Vicuna vocabulary exists offline) - and `clip.png`, a seeded 90 x 70 RGB image.  Expected output:
+the reference's own prompt template (`PROMPT_TEMPLATE.vicuna`, xtuner/utils/templates.py) and its own `process_text` (the function's source is
+executed from /root/reference/inference.py at generation time, with `.cuda()` made a no-op), HF `CLIPImageProcessor(size=56, crop_size=56)` (the
+reference passes its model's 378), then the stack above, greedy `generate` WITH the EOS rule, `tokenizer.batch_decode(..., skip_special_tokens=True)`.
 """
 import json
 import os
@@ -159,10 +166,81 @@ def build(R, seed):
     G.save("g13_checkpoint_e2e.npz", dict(R["versions"], transformers_pin_of_reference="<=4.42.4"), pixel_values=px.numpy().astype(np.float16),
            input_ids=ids.numpy(), ratio=np.array(RATIO), r=np.array(r), n_kept=np.array(n_kept), ids=gen_ids[0].numpy(), logits=logits.numpy(),
            vis_feats=feats.numpy(), embeds=emb[0].numpy())
+    g14(R, llm2, tower, enc, proj2, vc, gen)
     files = sorted(os.path.relpath(os.path.join(d, f), OUT) for d, _, fs in os.walk(OUT) for f in fs)
     print("\n".join(f"{os.path.getsize(os.path.join(OUT, f)):9d}  {f}" for f in files))
     print(json.dumps(json.load(open(os.path.join(OUT, "config.json"))), indent=None)[:600])
     return clear
+
+
+CORPUS = ["a chat between a curious user and an artificial intelligence assistant.",
+          "the assistant gives helpful, detailed, and polite answers to the user's questions.",
+          "USER: describe the video in detail. ASSISTANT:", "USER: what is shown in this image? ASSISTANT:",
+          "a person walks across the street while cars pass by.", "the quick brown fox jumps over the lazy dog.",
+          "two children play with a red ball on the grass near a house.", "the camera moves slowly from left to right over a city at night.",
+          "USER: \nDescribe the video in detail. ASSISTANT: The video shows a dog.", "What happens next?\nA man opens the door."]
+
+
+def g14(R, llm2, tower, enc, proj2, vc, gen):
+    import ast
+    from PIL import Image
+    from tokenizers import Tokenizer, decoders, models, normalizers, processors, trainers
+    from transformers import AutoTokenizer, CLIPImageProcessor, PreTrainedTokenizerFast
+    aurora, utils, consts, templates = R["aurora"], R["utils"], R["consts"], R["templates"]
+    # ---- tokenizer: Llama-style BPE (metaspace), ids 0 / 1 / 2 = <unk> / <s> / </s>, BOS prepended by encode() unless add_special_tokens=False
+    tk = Tokenizer(models.BPE(unk_token="<unk>"))
+    tk.normalizer = normalizers.Sequence([normalizers.Prepend("\u2581"), normalizers.Replace(" ", "\u2581")])
+    tk.decoder = decoders.Sequence([decoders.Replace("\u2581", " "), decoders.Fuse(), decoders.Strip(" ", 1, 0)])
+    tk.train_from_iterator(CORPUS * 10, trainers.BpeTrainer(vocab_size=300, special_tokens=["<unk>", "<s>", "</s>"]))
+    tk.post_processor = processors.TemplateProcessing(single="<s> $A", pair="<s> $A <s> $B", special_tokens=[("<s>", 1)])
+    assert tk.get_vocab_size() <= 320
+    PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<s>", eos_token="</s>", unk_token="<unk>", padding_side="right").save_pretrained(OUT)
+    tokenizer = AutoTokenizer.from_pretrained(OUT, padding_side="right")                        # inference.py:64-68
+    assert tokenizer.bos_token_id == 1 and tokenizer.eos_token_id == 2 and tokenizer.encode("the")[0] == 1
+    # ---- the reference's own process_text, executed from its source file
+    src = open(os.path.join(G.REF, "inference.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "process_text")
+
+    class _Torch:                                                                                # torch.tensor(ids).cuda() without a GPU
+        @staticmethod
+        def tensor(x):
+            t = torch.tensor(x)
+            t.cuda = lambda: t
+            return t
+    ns = {"DEFAULT_IMAGE_TOKEN": consts.DEFAULT_IMAGE_TOKEN, "IMAGE_TOKEN_INDEX": consts.IMAGE_TOKEN_INDEX, "torch": _Torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "reference:inference.py", "exec"), ns)
+    prompt = "Describe the video in detail."
+    text_input = consts.DEFAULT_IMAGE_TOKEN + "\n" + prompt                                      # inference.py:80-85 (image branch)
+    prompt_text = templates.PROMPT_TEMPLATE["vicuna"]["INSTRUCTION"].format(input=text_input, round=1)
+    ids = ns["process_text"](prompt_text, tokenizer)
+    processor = CLIPImageProcessor(size=vc.image_size, crop_size=vc.image_size)                  # inference.py:58-63 with the model's own size
+    enc.r = int(vc.image_size * vc.image_size / (vc.patch_size ** 2) * (1 - RATIO) / vc.num_hidden_layers)
+    for img_seed in range(1414, 1414 + 400):                                                      # first image whose caption has clear margins throughout
+        rng = np.random.default_rng(img_seed)
+        img = (rng.integers(0, 256, (70, 90, 3)).astype(np.float32) * 0.5 + np.linspace(0, 127, 90)[None, :, None]).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(OUT, "clip.png"))
+        image = Image.open(os.path.join(OUT, "clip.png"))
+        px = processor(image, return_tensors="pt")["pixel_values"].to(torch.float16)            # inference.py:79 (.to(dtype=torch.float16))
+        with torch.no_grad():
+            h = tower.pre_layrnorm(tower.embeddings(px.float()))
+            out = enc(h, output_hidden_states=True, return_dict=True)
+            feats = out.hidden_states[-2][:, 1:]
+            vo = proj2(feats.reshape(1, feats.shape[1], -1)).reshape(1, 1, feats.shape[1], -1)
+            data = utils.prepare_inputs_labels_for_multimodal(llm=llm2, input_ids=ids, pixel_values=vo)
+            emb = data["inputs_embeds"]
+            cont = llm2.generate(inputs_embeds=emb, attention_mask=None, do_sample=False, temperature=0.0, top_p=1.0, num_beams=1, max_new_tokens=NEW)
+            tok_emb = llm2.get_input_embeddings()(cont[0, :-1])[None] if cont.shape[1] > 1 else emb[:, :0]
+            logits = llm2(inputs_embeds=torch.cat([emb, tok_emb], dim=1)).logits[0, emb.shape[1] - 1:]
+        top2 = logits.topk(2, dim=-1).values
+        rel = ((top2[:, 0] - top2[:, 1]) / logits.abs().max()).tolist()
+        if cont.shape[1] >= 8 and min(rel) > 0.025 and bool((logits.argmax(-1) == cont[0]).all()):
+            break
+    else:
+        raise SystemExit("G14: no image with clear margins found")
+    text = tokenizer.batch_decode(cont, skip_special_tokens=True)[0]                            # inference.py:97
+    print("G14 prompt ids", ids.shape[1], "generated", cont[0].tolist(), "text", repr(text), "min margin", min(rel))
+    G.save("g14_cli_e2e.npz", dict(R["versions"]), prompt=np.array(prompt), prompt_text=np.array(prompt_text), input_ids=ids.numpy(),
+           pixel_values=px.numpy(), ids=cont[0].numpy(), logits=logits.numpy(), text=np.array(text), ratio=np.array(RATIO), new=np.array(NEW))
 
 
 if __name__ == "__main__":

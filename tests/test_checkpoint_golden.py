@@ -82,3 +82,30 @@ def test_shard_index_is_authoritative(tmp_path):
     os.remove(d / "model-00002-of-00003.safetensors")
     with pytest.raises(Exception):
         CK._load_state(str(d))
+
+
+def test_cli_path_pieces_against_the_reference_side_run():
+    """G14: the CLI path of inference.py:58-98 on the fixture directory - a real HF tokenizer (`AutoTokenizer.from_pretrained`), the
+    reference's prompt template and `process_text`, `CLIPImageProcessor` pixels, the reference-side stack, EOS-aware greedy decode and
+    `batch_decode`.  Here on the CPU: this repo's `build_prompt` / `process_text` give the reference's prompt and ids, the input-stage
+    restatement gives the processor's pixels bit for bit, and the oracle gives the same caption ids and text."""
+    from PIL import Image
+    from transformers import AutoTokenizer
+    from aurora_amd.model import build_prompt, process_text
+    from oracle import preprocess_ref as PR
+    g = np.load(os.path.join(HERE, "golden", "g14_cli_e2e.npz"))
+    tok = AutoTokenizer.from_pretrained(ROOT, padding_side="right")
+    prompt_text = build_prompt(str(g["prompt"]), 1)
+    assert prompt_text == str(g["prompt_text"])
+    ids = process_text(prompt_text, tok)
+    assert ids.tolist() == g["input_ids"].tolist() and ids[0, 0] == tok.bos_token_id
+    img = np.asarray(Image.open(os.path.join(ROOT, "clip.png")).convert("RGB"))
+    px = PR.clip_preprocess(img[None], 56)
+    assert np.array_equal(np.asarray(px).view(np.uint16), g["pixel_values"].view(np.uint16))          # fp16 bits of the processor's output
+    cfg, w = CK.load_auroracap(ROOT)
+    f32 = lambda t: {k: ([f32(x) for x in v] if isinstance(v, list) else v.float()) for k, v in t.items()}
+    w = {k: f32(v) for k, v in w.items()}
+    out = O.caption_ids(torch.from_numpy(g["pixel_values"]).float(), ids[0].tolist(), w, cfg, float(g["ratio"]), int(g["new"]),
+                        eos_id=cfg["llm"]["eos_token_id"], q=None)
+    assert out == g["ids"].tolist()
+    assert tok.batch_decode([out], skip_special_tokens=True)[0] == str(g["text"])

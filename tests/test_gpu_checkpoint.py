@@ -133,3 +133,24 @@ def test_fixture_not_written_by_this_repo_through_from_pretrained(visual, tmp_pa
         assert checked >= 8, (checked, got, g["ids"].tolist())
     finally:
         m.engine.close()
+
+
+def test_cli_on_the_fixture_prints_the_reference_side_caption():
+    """`python inference.py --model_path tests/golden/ckpt_tiny --visual_input .../clip.png` - the reference CLI's argument surface -
+    with a real HF tokenizer (AutoTokenizer on the fixture's tokenizer.json), the HIP input stage, from_pretrained on the directory HF /
+    the reference wrote, EOS-aware greedy decode and batch_decode: stdout must be the caption the HF + reference stack produced from
+    the same files (G14: every generated position has an oracle-side margin above 5 % of the logit scale)."""
+    import subprocess
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    fixture = os.path.join(here, "golden", "ckpt_tiny")
+    g = np.load(os.path.join(here, "golden", "g14_cli_e2e.npz"))
+    cmd = [sys.executable, os.path.join(root, "inference.py"), "--model_path", fixture, "--visual_input", os.path.join(fixture, "clip.png"),
+           "--prompt", str(g["prompt"]), "--token_kept_ratio", str(float(g["ratio"])), "--max_new_tokens", str(int(g["new"]))]
+    for extra in ([], ["--host_preprocess"]):                          # HIP input stage (default) and the reference's host processor
+        r = subprocess.run(cmd + extra, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stdout.rstrip("\n").split("\n")[-1] == str(g["text"]).split("\n")[-1], (r.stdout[-500:], str(g["text"]))
+        assert str(g["text"]) in r.stdout
