@@ -67,7 +67,10 @@ def main():
         vcfg = vit_config(osp.join(args.model_path, "visual_encoder"))
         image_size, patch = vcfg["image_size"], vcfg["patch_size"]
         if args.host_preprocess:      # the reference's host path (PIL); default is the bit-identical HIP input stage
-            image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=image_size, crop_size=image_size)
+            try:
+                image_processor = CLIPImageProcessor.from_pretrained("laion/CLIP-ViT-bigG-14-laion2B-39B-b160k", size=image_size, crop_size=image_size)
+            except OSError:           # no hub access: that repository's preprocessor_config.json holds the class defaults (OpenAI CLIP mean / std, bicubic)
+                image_processor = CLIPImageProcessor(size=image_size, crop_size=image_size)
 
             def to_pixels(frames):
                 return image_processor(list(frames), return_tensors='pt')['pixel_values'].to(dtype=torch.float16)
