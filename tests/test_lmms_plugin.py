@@ -239,3 +239,12 @@ def test_g12_prompts_and_ids_of_the_reference_adaptor_helpers():
         assert prompt == str(g[f"prompt{i}"]), i
         for tag, tok in (("bos", CharTok(True)), ("nobos", CharTok(False))):
             assert P.tokenizer_image_token(prompt, tok) == g[f"ids{i}_{tag}"].tolist(), (i, tag)
+    # round 3: the reference helper driven by a real HF tokenizer (fixture G14's, tests/golden/ckpt_tiny) - same ids from the restatement
+    import os
+    from transformers import AutoTokenizer
+    hf = AutoTokenizer.from_pretrained(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_tiny"), padding_side="right")
+    for i, (context, n_img) in enumerate(cases):
+        prompt = P.conv_prompt(P.question_with_image_tokens(context, n_img))
+        got = P.tokenizer_image_token(prompt, hf)
+        assert got == g[f"ids{i}_hf"].tolist(), i
+        assert got.count(P.IMAGE_TOKEN_INDEX) == max(n_img, prompt.count(P.DEFAULT_IMAGE_TOKEN)) and got[0] == hf.bos_token_id and got.count(hf.bos_token_id) == 1
