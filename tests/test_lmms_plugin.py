@@ -247,4 +247,4 @@ def test_g12_prompts_and_ids_of_the_reference_adaptor_helpers():
         prompt = P.conv_prompt(P.question_with_image_tokens(context, n_img))
         got = P.tokenizer_image_token(prompt, hf)
         assert got == g[f"ids{i}_hf"].tolist(), i
-        assert got.count(P.IMAGE_TOKEN_INDEX) == max(n_img, prompt.count(P.DEFAULT_IMAGE_TOKEN)) and got[0] == hf.bos_token_id and got.count(hf.bos_token_id) == 1
+        assert got.count(P.IMAGE_TOKEN_INDEX) == prompt.count(P.DEFAULT_IMAGE_TOKEN) and got[0] == hf.bos_token_id and got.count(hf.bos_token_id) == 1
