@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
     int nkb = (a.t + 63) >> 6;
     if (a.causal) {
-        const int lastq = qb * 128 + 127;
+        const int lastq = a.q_pos0 + qb * 128 + 127;
         const int lim = (lastq >> 6) + 1;
         nkb = nkb < lim ? nkb : lim;
     }
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         }
         h8 pf[2][2];
         // wave-uniform: unless every key of this block is valid for every query of this wave, mask first (diagonal / last block)
-        if (!((kb * 64 + 63 < a.t) && (!a.causal || kb * 64 + 63 <= q0))) {
+        if (!((kb * 64 + 63 < a.t) && (!a.causal || kb * 64 + 63 <= a.q_pos0 + q0))) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                const int query = q0 + qt * 16 + c;
+                const int query = a.q_pos0 + q0 + qt * 16 + c;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll

@@ -75,6 +75,8 @@ struct AttnArgs {
     int ldo;
     int hd;
     int nqb;                // filled by launch_attention: query blocks of 128 rows per sequence
+    int q_pos0;             // position of query row 0 of every sequence among its keys (causal mask): 0 = the Q buffer starts at the
+                            // sequence's first token; > 0 = it holds only a tail of the sequence (the pruned last prefill layer)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 

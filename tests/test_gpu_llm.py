@@ -345,3 +345,44 @@ def test_decode_attention_on_the_valu_matches_the_mfma_form(name):
             assert eng.generate([padded(embs[b])], [embs[b].shape[0]], 7, eos_id=None)[0] == ids3[b]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name,L,nseq", [("hd128", 300, 1), ("hd128", 709, 3), ("hd32", 431, 2), ("hd64", 512, 4)])
+def test_pruned_last_prefill_layer_is_bitwise_the_full_one(name, L, nseq):
+    """prefill_prune_last (default on): the last layer of a prefill computes K / V for every position but Q, attention, o_proj
+    and the MLP for each sequence's last 128 rows only (nothing later reads the other rows: HF computes and drops them,
+    modeling_llama forward -> generate keeps logits[:, -1]).  Every value that survives is produced by the same operations in
+    the same order, so first-token logits, the following decode logits (which read the last layer's K / V of ALL positions)
+    and the ids must be bitwise those of the unpruned layer - one sequence and a multi-sequence pass alike, and the last
+    hidden rows handed back in place."""
+    cfg = LLM_CFGS[name]
+    eng, w = make_engine(cfg, 31, max_batch=nseq, use_graph=False, max_ctx=1024, max_new=10)
+    try:
+        gen = torch.Generator().manual_seed(7 * L + nseq)
+        lp = (L + 31) // 32 * 32
+        emb = torch.zeros(nseq, lp, cfg["hidden_size"], dtype=torch.float16, device="cuda")
+        emb[:, :L] = (torch.randn(nseq, L, cfg["hidden_size"], generator=gen)).half().cuda()
+        outs = {}
+        for prune in (0, 1):
+            eng.set_option("prefill_prune_last", prune)
+            eng.begin_batch(nseq, 10, None)
+            x = emb.clone()
+            if nseq == 1:
+                eng.prefill(0, x[0], L)
+            else:
+                eng.prefill_batch(0, nseq, x.view(nseq * lp, -1), L)
+            first = eng.logits().clone()
+            logits = []
+            for _ in range(5):
+                eng.decode(1)
+                logits.append(eng.logits().clone())
+            torch.cuda.synchronize()
+            outs[prune] = (first, torch.stack(logits), eng.outputs(), x[:, L - 1].clone(), x[:, : lp - 128].clone())
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2]
+        assert torch.equal(outs[0][3], outs[1][3])           # the last position's final hidden state, in place
+        assert not torch.equal(outs[0][4], outs[1][4])       # ... and the pruning really happened: the other rows stop one layer early
+    finally:
+        eng.set_option("prefill_prune_last", 1)
+        eng.close()
