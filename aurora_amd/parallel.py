@@ -23,7 +23,8 @@ def gather_results(local_ids: Sequence[Sequence[int]], max_new_tokens: int, clip
 
     Wire format: int32 [clips_per_rank, 1 + max_new_tokens] per rank (col 0 = length, -1 = no clip)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    live = dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
     buf = torch.full((clips_per_rank, 1 + max_new_tokens), -1, dtype=torch.int32)
     for i, ids in enumerate(local_ids):
         n = min(len(ids), max_new_tokens)
@@ -31,7 +32,7 @@ def gather_results(local_ids: Sequence[Sequence[int]], max_new_tokens: int, clip
         if n:
             buf[i, 1:1 + n] = torch.tensor(list(ids)[:n], dtype=torch.int32)
     buf = buf.to(device)
-    if world == 1:
+    if not live:
         bufs = [buf]
     else:
         bufs = [torch.empty_like(buf) for _ in range(world)]

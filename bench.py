@@ -283,8 +283,11 @@ def main():
     if backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
+    # AURORA_DIST_FORCE=1 is a TEST hook too: a ONE-rank launch still opens the process group and makes every collective of the multi-rank
+    # path (the only way to run the RCCL branch on a one-GPU box: `torchrun --nproc-per-node 1 bench.py --gpus 1`)
+    use_dist = world > 1 or os.environ.get("AURORA_DIST_FORCE") == "1"
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         if backend == "nccl":
             if torch.cuda.device_count() < world:
@@ -394,12 +397,12 @@ def main():
         else:
             eng.decode(N - 1)
         out = eng.outputs()
-        if world > 1 and gather:
+        if use_dist and gather:
             parallel.gather_results(out, N, B, cdev)               # RCCL all_gather over xGMI
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -463,7 +466,7 @@ def main():
                 return None
             got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()         # synchronises: the cycle has run
             o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
-            if world > 1:
+            if use_dist:
                 parallel.gather_results(o, N, B, cdev)             # RCCL all_gather over xGMI, once per cycle
             return o
 
@@ -601,7 +604,7 @@ def main():
                         sD.synchronize()
                 got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
                 o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
-                if world > 1:
+                if use_dist:
                     parallel.gather_results(o, N, B, cdev)
                 return o
 
@@ -700,8 +703,10 @@ def main():
             ttft_ms.extend(ev0.elapsed_time(e) for e in evs)
         eng.select_bank(0)
     assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
+    import zlib
+    ids_checksum = zlib.crc32(np.asarray(out, dtype=np.int32).tobytes())     # of this rank's last step: the same command must reproduce it
     per_rank_ms, gather_us = None, None
-    if world > 1:
+    if use_dist:
         # every rank's own clock around the same K steps (the line's time is their MAX), so that a slow rank or a slow link shows in
         # the record itself; and the cost of the one collective of the path, timed on its own after the steps
         mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -724,8 +729,8 @@ def main():
         result = {
             "metric": "captions/sec (AuroraCap-7B, %d-frame clips, token_kept_ratio %g, %d new tokens) + p50 TTFT" % (F, args.token_kept_ratio, N),
             "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "rccl_ranks": world if (world > 1 and backend == "nccl") else (0 if world > 1 else 1), "dist_backend": backend if world > 1 else "none",
-            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_per_rank": per_rank_ms, "ids_all_gather_us": gather_us,
+            "rccl_ranks": world if (use_dist and backend == "nccl") else (0 if use_dist else 1), "dist_backend": backend if use_dist else "none",
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_per_rank": per_rank_ms, "ids_all_gather_us": gather_us, "ids_checksum_rank0": ids_checksum,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[%d]%s)"
@@ -911,7 +916,7 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(ex)}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()                                             # rank 0 arrives last (instrumented pass): leave together
         dist.destroy_process_group()
 

@@ -116,6 +116,30 @@ def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     assert d["ids_all_gather_us"] > 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--batch-mode"]])
+def test_one_rank_over_rccl_runs_every_collective_of_the_multi_rank_path(extra):
+    """The RCCL branch on a ONE-GPU box: `torchrun --nproc-per-node 1 bench.py --gpus 1` with AURORA_DIST_FORCE=1 opens the `nccl`
+    process group on the device (`device_id=`), and every collective of the N-rank path really runs through RCCL with device
+    tensors - the GPU-ordinal probe, the barriers around the timed steps, the per-cycle ids all_gather
+    (`parallel.gather_results`), the per-rank clocks and the gather latency.  (What a 2-GPU node adds - xGMI transport between
+    ranks - is the test above.)  The ids are the ones the same run produces without a process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "AURORA_DIST_BACKEND")}
+    env.update(AURORA_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1"] + TINY + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["value"] > 0
+    assert len(d["ms_per_step_per_rank"]) == 1 and d["ms_per_step_per_rank"][0] == pytest.approx(d["ms_per_step"])
+    assert d["ids_all_gather_us"] > 0
+    env.pop("AURORA_DIST_FORCE")
+    r0 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + TINY + extra, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r0.returncode == 0, r0.stderr[-3000:]
+    d0 = _json_line(r0.stdout)
+    assert d0["dist_backend"] == "none" and d0["ids_checksum_rank0"] == d["ids_checksum_rank0"]
+
+
 def test_config_presets_and_self_diagnosing_fields():
     """`--config cfgN` names a BASELINE.json config; explicit flags still win; the two-rank line carries per-rank times and the
     gather latency; the overlapped schedule reports a host-observed TTFT beside the device-event one."""
