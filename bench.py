@@ -270,6 +270,17 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def overlap_pays(slots: int, prefill_len: int, new_tokens: int, llm: dict) -> bool:
+    """Schedule rule of the default (`--overlap -1`) mode.  The front end beside the decode pays only while the decode step is dominated by
+    the K / V stream, which half of the CUs can pull: a step of few slots is the 13 GB weight stream through projections that want every
+    CU, and masking it costs more than the overlap returns (cfg4, 8 slots: 5.4 captions/s overlapped against 5.8 with the front ends
+    between the chunks; cfg2 / cfg3, 128 / 96 slots: 13.6 against 11.4 and 5.8 against 5.3)."""
+    L, h, m, V = llm["num_hidden_layers"], llm["hidden_size"], llm["intermediate_size"], llm["vocab_size"]
+    kv_step = slots * (prefill_len + new_tokens / 2) * 4 * L * h           # fp16 K + V of every cached token, mean context of a cycle
+    w_step = 2 * (L * (4 * h * h + 3 * h * m) + V * h)                      # fp16 layer weights + lm_head
+    return kv_step >= w_step
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -329,6 +340,8 @@ def main():
     L0 = 30 + F * n_kept
     max_ctx = _rup(L0 + N, 64)
     want_overlap = args.overlap != 0 and not (args.batch_mode or pipe or args.decode_chunk > 0)
+    if args.overlap < 0 and want_overlap and not args.tiny:        # (tiny dims are plumbing runs: they keep the default schedule)
+        want_overlap = overlap_pays(B, L0, N, l)
     G = max(1, min(args.prefill_group if args.prefill_group > 0 else (4 if want_overlap else 8), B))
     VC = B if args.vit_chunk <= 0 else max(G, args.vit_chunk // G * G)       # clips per ViT pass: a multiple of G
     overlap = want_overlap and B % G == 0 and B // G >= 2 and N >= 2 * (B // G)         # = the continuous mode applies
@@ -505,6 +518,11 @@ def main():
             #      mask (the front end is in flight), the rest unmasked.
             half_grid = 1 if args.half_grid else 0
             k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, int(round(0.8 * (S // NG))))
+            # ... but never more steps than the front end needs: a chunk of a small-batch or long-caption config (cfg4: 127 steps, cfg5: 170)
+            # is much longer than its front end, and every masked step beyond it runs on half of the CUs for nothing.  The warm-up
+            # cycle measures the front end's duration beside the masked decode and the masked step: k = ceil(T_front / t_step),
+            # capped by the 0.8-chunk rule (which is what binds in the default config, where a chunk IS a front end long).
+            k_cal = {"front_ev": [], "dec_ev": [], "on": False, "info": None}
             sD = torch.cuda.current_stream()
             sF = masked[0]
             sDm = masked[1] if k_masked > 0 else None
@@ -564,8 +582,10 @@ def main():
                     for j in range(G):
                         eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
                     eng.prefill_stage(B, G, emb_all, L0)
-                    evf = torch.cuda.Event()
+                    evf = torch.cuda.Event(enable_timing=k_cal["on"])
                     evf.record(sF)
+                if k_cal["on"]:
+                    k_cal["front_ev"].append((e0, evf))
                 front_seq[0] += 1
                 start_q.put((front_seq[0], e0))
                 return e0, evf, (front_seq[0], t_host)
@@ -594,11 +614,16 @@ def main():
                     if k1 > 0:
                         sDm.wait_event(e1)
                         with torch.cuda.stream(sDm):
+                            if k_cal["on"]:
+                                evm0 = torch.cuda.Event(enable_timing=True)
+                                evm0.record(sDm)
                             eng.set_option("decode_half_grid", half_grid)   # half as many workgroups, twice the tiles each
                             eng.decode(k1)
                             eng.set_option("decode_half_grid", 0)
-                            evm = torch.cuda.Event()
+                            evm = torch.cuda.Event(enable_timing=k_cal["on"])
                             evm.record(sDm)
+                            if k_cal["on"]:
+                                k_cal["dec_ev"].append((evm0, evm, k1))
                         sD.wait_event(evm)
                     if n - k1 > 0:
                         eng.decode(n - k1)
@@ -614,9 +639,20 @@ def main():
 
             sF.wait_stream(sD)
             pending[0] = front_async(0)
+            k_cal["on"] = args.overlap_steps < 0 and sDm is not None      # measured during the warm-up cycle(s) below, applied after them
         for _ in range(max(args.warmup - 1, 1 if overlap else 0)):  # overlap: the first front end above overlapped nothing
             cycle(False, False)
         fence()
+        if overlap and k_cal["on"]:
+            k_cal["on"] = False
+            t_front = float(np.median([a.elapsed_time(b) for a, b in k_cal["front_ev"][:-1]]))      # the last one ran beside nothing (fence)
+            t_step = float(np.median([a.elapsed_time(b) / k for a, b, k in k_cal["dec_ev"]]))
+            k_need = int(np.ceil(t_front / max(t_step, 1e-3)))
+            k_cal["info"] = {"front_end_ms_beside_masked_decode": t_front, "masked_decode_step_ms": t_step, "steps_needed": k_need,
+                             "cap_0p8_chunk": k_masked}
+            k_masked = max(1, min(k_masked, k_need))
+            k_cal["front_ev"].clear()
+            k_cal["dec_ev"].clear()
         sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None
         t_start = time.perf_counter()
         outs = []
@@ -752,6 +788,7 @@ def main():
                                    "spare KV sequences, committed at the group's boundary; %d decode steps per chunk on the other %d CUs per XCD)"
                                    % (fc, k_masked, 32 - fc) if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
+            "overlap_steps_calibration": (k_cal["info"] if (continuous and overlap) else None),
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "power": power,
             "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
