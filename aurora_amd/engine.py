@@ -507,7 +507,8 @@ class AuroraCapEngine:
         on_error(index, exception): a clip whose front end is rejected (shape, context longer than max_ctx, ...) is reported
         and skipped while the captions in flight keep going (the reference harness turns a failing request into an empty
         caption, lmms_eval/models/auroracap.py:511-514); None = raise.
-        overlap (default: on when the engine was built with spare_slots > 0): the front ends of the NEXT clips run ahead on
+        overlap (default: on when the engine was built with spare_slots > 0; whoever builds the engine decides with
+        `streams.overlap_pays` whether a decode of that many slots is K / V-bound enough for it): the front ends of the NEXT clips run ahead on
         their own stream, restricted to `front_cus` CUs of every XCD, into the spare KV sequences while every slot keeps
         decoding (decode is HBM-bound, ViT + prefill MFMA-bound); a freed slot takes over a prepared clip's pages at the next
         check (`prefill_commit`).  Same ids either way."""

@@ -74,3 +74,15 @@ def cu_masked_stream(cus_per_xcd: int, from_top: bool = False, device=None) -> "
     if rc != 0 or not st.value:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with status {rc}")
     return torch.cuda.ExternalStream(st.value, device=dev)
+
+
+def overlap_pays(slots: int, mean_ctx: float, llm: dict) -> bool:
+    """Does a front end beside the decode (CU-masked streams) pay for a decode of `slots` sequences at a mean context of `mean_ctx` tokens?
+    Only while the decode step is dominated by the K / V stream, which half of the CUs can pull: a step of few slots is the weight stream
+    through projections that want every CU, and masking it costs more than the overlap returns (measured with the 7B dims, bench.py:
+    8 slots 5.4 captions/s overlapped against 5.8 with the front ends between the chunks; 96 / 128 slots 5.8 against 5.3 and 13.6
+    against 11.4)."""
+    L, h, m, V = llm["num_hidden_layers"], llm["hidden_size"], llm["intermediate_size"], llm["vocab_size"]
+    kv_step = slots * mean_ctx * 4 * L * h                    # fp16 K + V of every cached token
+    w_step = 2 * (L * (4 * h * h + 3 * h * m) + V * h)        # fp16 layer weights + lm_head
+    return kv_step >= w_step

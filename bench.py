@@ -271,14 +271,10 @@ def self_launch(n: int) -> int:
 
 
 def overlap_pays(slots: int, prefill_len: int, new_tokens: int, llm: dict) -> bool:
-    """Schedule rule of the default (`--overlap -1`) mode.  The front end beside the decode pays only while the decode step is dominated by
-    the K / V stream, which half of the CUs can pull: a step of few slots is the 13 GB weight stream through projections that want every
-    CU, and masking it costs more than the overlap returns (cfg4, 8 slots: 5.4 captions/s overlapped against 5.8 with the front ends
-    between the chunks; cfg2 / cfg3, 128 / 96 slots: 13.6 against 11.4 and 5.8 against 5.3)."""
-    L, h, m, V = llm["num_hidden_layers"], llm["hidden_size"], llm["intermediate_size"], llm["vocab_size"]
-    kv_step = slots * (prefill_len + new_tokens / 2) * 4 * L * h           # fp16 K + V of every cached token, mean context of a cycle
-    w_step = 2 * (L * (4 * h * h + 3 * h * m) + V * h)                      # fp16 layer weights + lm_head
-    return kv_step >= w_step
+    """Schedule rule of the default (`--overlap -1`) mode: front ends beside the decode only where the decode step is dominated by the
+    K / V stream (aurora_amd.streams.overlap_pays at the cycle's mean context; cfg4's 8 slots keep their front ends out of the decode)."""
+    from aurora_amd.streams import overlap_pays as pays
+    return pays(slots, prefill_len + new_tokens / 2, llm)
 
 
 def main():
