@@ -181,6 +181,8 @@ def test_constructor_plumbing_reaches_from_pretrained_with_config_derived_capaci
     (tmp_path / "visual_encoder").mkdir()
     (tmp_path / "visual_encoder" / "config.json").write_text(json.dumps(dict(
         hidden_size=64, num_attention_heads=4, num_hidden_layers=8, intermediate_size=128, patch_size=16, image_size=64)))
+    (tmp_path / "config.json").write_text(json.dumps(dict(                      # the language model's config.json: vicuna-7b dims
+        hidden_size=4096, num_attention_heads=32, num_hidden_layers=32, intermediate_size=11008, vocab_size=32000)))
     seen = {}
 
     class StubModel:
@@ -202,6 +204,10 @@ def test_constructor_plumbing_reaches_from_pretrained_with_config_derived_capaci
     assert seen["max_frames"] == 5 and seen["max_batch"] == 3 and seen["max_new_tokens"] == 100 and seen["device"] == "cuda"
     assert seen["max_ctx"] == 256 + 5 * 9 + 100
     assert m.world_size == 1 and not hasattr(m, "accelerator")
+    # front ends are prefetched beside the decode (spare KV sequences) only where that many slots make a K / V-bound decode step
+    assert seen["spare_slots"] == 0                                              # 3 slots x 200 tokens of context: the weight stream
+    P.AuroraCapMI355X(pretrained=str(tmp_path), resolution=64, token_merge_ratio=0.5, batch_size=64, max_frames_num=4, max_new_tokens=2000)
+    assert seen["max_batch"] == 64 and seen["spare_slots"] == 4                  # 64 slots x ~1.2 k tokens: K / V-bound
 
 
 def test_engine_device_normalisation(monkeypatch):
