@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][qt][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             // the softmax is VALU-bound (27-31 % MFMA busy, PMC): after the first few key blocks a query's running maximum rarely
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         const float inv = 1.0f / l;
         const int query = q0 + qt * 16 + c;
         if (query < a.rows_per_seq) {

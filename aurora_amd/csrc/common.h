@@ -38,15 +38,50 @@ __device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+// Lane exchanges over the 4 rows of 16 lanes on the VALU (gfx950: v_permlane16_swap / v_permlane32_swap) instead of ds_bpermute_b32
+// through the LDS crossbar (~100+ cycles of latency behind the same lgkmcnt as the kernel's real LDS reads).  Both lanes of a pair
+// compute `own op partner` from the same two values and + / max are commutative: results are BITWISE those of
+// `v op __shfl_xor(v, 16)` / `(.., 32)`.  swap16(A, B): A.row1 <-> B.row0, A.row3 <-> B.row2; swap32(A, B): A.rows23 <-> B.rows01.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) { return xor32_sum(xor16_sum(v)); }      // over the 4 lanes l, l ^ 16, l ^ 32, l ^ 48 (16 first)
+__device__ __forceinline__ float rows_max(float v) { return xor32_max(xor16_max(v)); }
+// max over the 16 lanes of a row, in every lane of it: DPP row rotations (order does not matter for max)
+__device__ __forceinline__ float row16_max(float v) {
+#define AUR_ROR(x, n) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x120 + (n), 0xf, 0xf, false))
+    v = fmaxf(v, AUR_ROR(v, 8));
+    v = fmaxf(v, AUR_ROR(v, 4));
+    v = fmaxf(v, AUR_ROR(v, 2));
+    v = fmaxf(v, AUR_ROR(v, 1));
+#undef AUR_ROR
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {      // same pairing order as before (32, 16, 8, ..): bitwise unchanged
+    v = xor32_sum(v);
+    v = xor16_sum(v);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = xor32_max(v);
+    v = xor16_max(v);
+    return row16_max(v);
 }
 
 // x * sigmoid(k x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction IEEE division: these run 128 times

@@ -131,8 +131,8 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const int tile
                         p += (float)o[i] * (float)o[i];
                     }
                     *(h4*)px = o;
-                    p += __shfl_xor(p, 16, 64);
-                    p += __shfl_xor(p, 32, 64);
+                    p = xor16_sum(p);
+                    p = xor32_sum(p);
                     if (g == 0 && a.ssq_out)
                         atomicAdd(a.ssq_out + (tile & (AUR_SSQ_SLOTS - 1)) * AUR_MAX_BATCH + b, (unsigned long long)__float2ll_rn(p * SSQ_SCALE));
                 }
@@ -952,8 +952,8 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecAttnArgs a) {
                     mx = fmaxf(mx, v);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // key0 < npos => m_new finite
             m_run = m_new;
@@ -978,8 +978,8 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecAttnArgs a) {
         }
     }
     float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_sum(l);
+    l = xor32_sum(l);
     if ((lane & 15) == 0) {
 #pragma unroll
         for (int d = 0; d < VD16; ++d)
@@ -1060,8 +1060,8 @@ __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
                 mx = fmaxf(mx, v);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
@@ -1089,8 +1089,8 @@ __global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
         }
     }
     float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_sum(l);
+    l = xor32_sum(l);
     if (a.nsplit == 1) {
         // one split covers the whole context (engines whose batch alone fills the GPU: sequences x heads >= 512 waves): the
         // wave owns the final softmax, so it writes the attention output itself, straight in x-fragment form (input of the o
@@ -1184,8 +1184,8 @@ __global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a)
                 s[kt][i] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
@@ -1209,8 +1209,8 @@ __global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a)
         }
     }
     float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_sum(l);
+    l = xor32_sum(l);
     if (a.nsplit == 1) {
         if ((lane & 15) == 0) {
 #pragma unroll
@@ -1311,14 +1311,13 @@ __global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             float v = s[kt];
-            v += __shfl_xor(v, 16, 64);                   // the 4 dim groups of token kt * 16 + r: every one of its 4 lanes gets the same bits
-            v += __shfl_xor(v, 32, 64);
+            v = xor16_sum(v);                   // the 4 dim groups of token kt * 16 + r: every one of its 4 lanes gets the same bits
+            v = xor32_sum(v);
             v = (key0 + kt * 16 + r) < npos ? v * sc : -INFINITY;
             s[kt] = v;
             mx = fmaxf(mx, v);
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));      // over the 16 token lanes (the 4 groups already agree)
+        mx = row16_max(mx);                               // over the 16 token lanes (the 4 groups already agree); DPP, order-free
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
@@ -1351,8 +1350,8 @@ __global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
     for (int o = 1; o < 16; o <<= 1) l += __shfl_xor(l, o, 64);       // over the token lanes; the 4 groups hold the same sum
 #pragma unroll
     for (int d = 0; d < VD16; ++d) {                      // the 4 token groups of a feature
-        acc_o[d] += __shfl_xor(acc_o[d], 16, 64);
-        acc_o[d] += __shfl_xor(acc_o[d], 32, 64);
+        acc_o[d] = xor16_sum(acc_o[d]);
+        acc_o[d] = xor32_sum(acc_o[d]);
     }
     if (a.nsplit == 1) {
 #pragma unroll
