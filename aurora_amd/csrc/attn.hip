@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         const char* base = smem + (kb & 1) * (NF * 1024);
 
         f4 s[4][2];
+        __builtin_amdgcn_s_setprio(1);                 // MFMA groups at raised priority: the SIMD's other wave issues its softmax in the gaps
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             s[kt][0] = f4{0.f, 0.f, 0.f, 0.f};
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 s[kt][1] = mfma16(kf, qf[1][b], s[kt][1]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         h8 pf[2][2];
         // wave-uniform: unless every key of this block is valid for every query of this wave, mask first (diagonal / last block)
         if (!((kb * 64 + 63 < a.t) && (!a.causal || kb * 64 + 63 <= a.q_pos0 + q0))) {
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 l_run[qt] = l_run[qt] + ps;
             }
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int d = 0; d < VD16; ++d)
 #pragma unroll
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 acc_o[d][0] = mfma16(vf, pf[0][b32], acc_o[d][0]);
                 acc_o[d][1] = mfma16(vf, pf[1][b32], acc_o[d][1]);
             }
+        __builtin_amdgcn_s_setprio(0);
     }
 
 #pragma unroll
