@@ -394,6 +394,10 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     const int nchunk = (KE + KC - 1) / KC;
 
     if (w >= NCW) {                                            // ---------------- loader waves (piece q of a chunk -> loader q % NL)
+        // few instructions, all on the critical path of every consumer wave.  Measured per mode at 128 rows (tools/gpu/run_ab.sh): the
+        // split-K residual projections gain on a stream that owns half of the CUs (down 45.0 -> 43.0 us, o 27.0 -> 25.9 us; the same
+        // on all CUs), QKV loses (60.7 -> 64.6 us), gate/up does not care
+        if constexpr (MODE == SK_ROW) __builtin_amdgcn_s_setprio(3);
         const int lw = w - NCW;
         auto issue = [&](int ci) {
             char* buf = smem + (ci % NBUF) * CHUNK_BYTES;
