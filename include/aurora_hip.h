@@ -191,7 +191,10 @@ int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size,
 /* Copy the last-position logits of the most recent prefill / decode step into dst_dev: fp32 [batch, vocab]. */
 int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 
-/* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 0/1, "dec_attn_pps" pages per
+/* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 4 (default: v_dot2c page pipeline) / 1 (MFMA page pipeline) /
+ * 3 (the same with two waves per SIMD) / 2 (default-policy K / V loads) / 0 (un-pipelined), "decode_fused_reduce" 0 (default: the split-K
+ * residual projections are followed by a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same),
+ * "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
@@ -200,7 +203,10 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * kernel goes to the 128x128 kernel over the bottom rows) / 0, "microbench_prefill_nseq" sequences per pass for the pre_*
  * microbenchmarks.  "decode_half_grid" 1 / 0 does NOT invalidate the graphs (one is kept per setting): the next aur_llm_decode
  * calls go to a stream that owns half of the CUs, so the QKV / gate-up projections launch half as many workgroups with twice the
- * tiles each - bitwise the same tokens.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;
+ * tiles each - bitwise the same tokens.  "prefill_prune_last" 1 (default) / 0: the last layer of a prefill computes K / V for every
+ * position and the rest for each sequence's last 128 rows only - nothing else is read after it; bitwise the same logits and K / V; no graph
+ * is affected.  The gemm_* knobs (incl. "gemm_tile_order" 2, "gemm_lab" 0..7: lab variants, timing only) keep the graphs as well: no GEMM
+ * is part of the captured decode step.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;
  * the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
 /* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
