@@ -606,7 +606,11 @@ class AuroraCapEngine:
                     if k1 > 0:
                         sDm.wait_stream(sD)
                         with torch.cuda.stream(sDm):
+                            # on half of the CUs the QKV / gate-up projections launch half as many workgroups with twice the tiles each
+                            # (bitwise the same tokens; engines of <= 64 slots ignore it)
+                            self.set_option("decode_half_grid", 1)
                             self.decode(k1)
+                            self.set_option("decode_half_grid", 0)
                         sD.wait_stream(sDm)
                     if check_every - k1 > 0:
                         self.decode(check_every - k1)

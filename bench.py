@@ -77,10 +77,11 @@ def parse():
     p.add_argument("--overlap-steps", type=int, default=-1,
                    help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
                         "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
-    p.add_argument("--half-grid", action="store_true",
-                   help="--overlap 1 A/B: masked decode steps launch the QKV / gate-up projections with half as many workgroups and twice the "
-                        "tiles each (decode_half_grid; 43 vs 62 us and 49 vs 63 us alone on 16 CUs per XCD, but 13.66 vs 13.72 captions/s "
-                        "next to a running front end: the contended resource is bandwidth, not the x re-reads)")
+    p.add_argument("--half-grid", type=int, default=1, choices=[0, 1], nargs="?", const=1,
+                   help="--overlap 1: masked decode steps launch the QKV / gate-up projections with half as many workgroups and twice the "
+                        "tiles each (decode_half_grid: x crosses a CU's LDS once instead of twice; 41.5 vs 60.8 us and 48.0 vs 62.7 us on 16 "
+                        "CUs per XCD at 10-12 %% less energy per launch, bitwise the same tokens).  Default 1 since round 3: 14.00-14.02 "
+                        "against 13.64-13.85 captions/s, three alternating pairs on one box (round 2: 13.66 vs 13.72); 0 = full grid")
     p.add_argument("--sync-chunks", action="store_true",
                    help="--overlap 1: synchronise the decode stream after every chunk (profiling aid: rocprofv3 --kernel-trace needs the "
                         "queue of pending hipGraph launches kept short; costs a host round trip per chunk)")
@@ -512,7 +513,7 @@ def main():
             #      sequences B .. B + G - 1, and at the group's boundary aur_llm_prefill_commit (decode stream) exchanges page-table
             #      rows and produces the first tokens.  The first `k_masked` decode steps of a chunk run on the complementary
             #      mask (the front end is in flight), the rest unmasked.
-            half_grid = 1 if args.half_grid else 0
+            half_grid = 1 if args.half_grid else 0                # default 1
             k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, int(round(0.8 * (S // NG))))
             # ... but never more steps than the front end needs: a chunk of a small-batch or long-caption config (cfg4: 127 steps, cfg5: 170)
             # is much longer than its front end, and every masked step beyond it runs on half of the CUs for nothing.  The warm-up
@@ -783,6 +784,7 @@ def main():
                                 + ("; the front ends run on their own stream on %d CUs of every XCD while all slots decode (staged prefill into "
                                    "spare KV sequences, committed at the group's boundary; %d decode steps per chunk on the other %d CUs per XCD)"
                                    % (fc, k_masked, 32 - fc) if overlap else "")) if continuous else "batch: front end of all clips, then B-wide decode",
+                       "decode_half_grid_on_masked_steps": bool(args.half_grid) if (continuous and overlap) else None,
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "overlap_steps_calibration": (k_cal["info"] if (continuous and overlap) else None),
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
