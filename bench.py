@@ -514,11 +514,13 @@ def main():
             #      rows and produces the first tokens.  The first `k_masked` decode steps of a chunk run on the complementary
             #      mask (the front end is in flight), the rest unmasked.
             half_grid = 1 if args.half_grid else 0                # default 1
-            k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, int(round(0.8 * (S // NG))))
+            # cap: the whole steps of a chunk (chunks are S // NG or S // NG + 1 steps long).  Rounds 2-3 used four fifths of that; with the
+            # masked steps on the half grid one more masked step pays (7 against 6 of ~8: +0.45 %, three alternating pairs, r03_sched_sweep4)
+            k_masked = args.overlap_steps if args.overlap_steps >= 0 else max(1, S // NG)
             # ... but never more steps than the front end needs: a chunk of a small-batch or long-caption config (cfg4: 127 steps, cfg5: 170)
             # is much longer than its front end, and every masked step beyond it runs on half of the CUs for nothing.  The warm-up
             # cycle measures the front end's duration beside the masked decode and the masked step: k = ceil(T_front / t_step),
-            # capped by the 0.8-chunk rule (which is what binds in the default config, where a chunk IS a front end long).
+            # capped by the chunk's whole steps (which is what binds in the default config, where a chunk IS a front end long).
             k_cal = {"front_ev": [], "dec_ev": [], "on": False, "info": None}
             sD = torch.cuda.current_stream()
             sF = masked[0]
@@ -646,7 +648,7 @@ def main():
             t_step = float(np.median([a.elapsed_time(b) / k for a, b, k in k_cal["dec_ev"]]))
             k_need = int(np.ceil(t_front / max(t_step, 1e-3)))
             k_cal["info"] = {"front_end_ms_beside_masked_decode": t_front, "masked_decode_step_ms": t_step, "steps_needed": k_need,
-                             "cap_0p8_chunk": k_masked}
+                             "cap_whole_steps_of_a_chunk": k_masked}
             k_masked = max(1, min(k_masked, k_need))
             k_cal["front_ev"].clear()
             k_cal["dec_ev"].clear()
