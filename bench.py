@@ -76,7 +76,7 @@ def parse():
                         "(11.4 captions/s against 13.6-13.7 with 1 on one MI355X); -1 = auto (1 whenever the continuous mode applies)")
     p.add_argument("--overlap-steps", type=int, default=-1,
                    help="--overlap 1: decode steps per chunk that run on the complementary CU mask (the rest of the chunk runs unmasked); "
-                        "-1 = four fifths of a chunk (measured at chunks of 16: 0 -> 12.4, 12 -> 13.2, 16 -> 12.8 captions/s)")
+                        "-1 = as many as the front end needs (measured in the warm-up cycle), at most a chunk's whole steps")
     p.add_argument("--half-grid", type=int, default=1, choices=[0, 1], nargs="?", const=1,
                    help="--overlap 1: masked decode steps launch the QKV / gate-up projections with half as many workgroups and twice the "
                         "tiles each (decode_half_grid: x crosses a CU's LDS once instead of twice; 41.5 vs 60.8 us and 48.0 vs 62.7 us on 16 "
