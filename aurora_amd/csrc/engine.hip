@@ -76,8 +76,6 @@ struct aur_ctx {
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
-    int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
-    int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel (measured: no faster - off)
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
     // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
@@ -263,7 +261,6 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
-    c->d_row_cnt = k.take<int>(c->l_dpad / 16);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
@@ -341,7 +338,6 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     ctx->finalized = false;
     // arrival counters of the ToMe match + select launch: zero now, and every launch leaves them at zero
     if (ctx->w_tome_cnt) CK(hipMemset(ctx->w_tome_cnt, 0, (size_t)ctx->cfg.max_frames * 4));
-    if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -1060,7 +1056,6 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
     o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
     o.variant = ctx->skinny_variant; o.part = (d >= ctx->row_split_min_k || ctx->cfg.max_batch > 64) ? ctx->d_part_row : nullptr;
-    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -1080,7 +1075,6 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
     dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
     dn.variant = ctx->skinny_variant; dn.part = (g.llm_mlp >= ctx->row_split_min_k || g.max_batch > 64) ? ctx->d_part_row : nullptr;
-    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
     return dn;
 }
 
@@ -1227,12 +1221,6 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
-    } else if (!strcmp(name, "decode_fused_reduce")) {
-        // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (last-arriving split);
-        // 0 (default): a second launch does (skinny_row_reduce_kernel).  Bitwise the same tokens; measured at 128 slots: o 19.4 -> 18.4 us,
-        // down 28.6 -> 28.5 us, decode step 25.52 -> 25.53 ms - the hand-over's three global round trips cost what the launch costs, so
-        // the form without a cross-workgroup protocol stays the default.
-        ctx->fused_reduce = value ? 1 : 0;
     } else if (!strcmp(name, "decode_half_grid")) {
         // the following aur_llm_decode calls go to a stream that owns half of the CUs: QKV / gate-up launch half as many workgroups
         // with twice the tiles (decode.hip launch_skx_nb); bitwise the same tokens.  Keeps both captured graphs.
