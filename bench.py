@@ -269,6 +269,13 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def masked_steps_per_chunk(front_ms: float, step_ms: float, chunk_steps: int) -> int:
+    """Decode steps of a chunk that run on the decode mask: as many as the front end lasts beside them (both measured in the warm-up
+    cycle), at most the chunk's whole steps, at least one."""
+    need = int(np.ceil(front_ms / max(step_ms, 1e-3)))
+    return max(1, min(int(chunk_steps), need))
+
+
 def overlap_pays(slots: int, prefill_len: int, new_tokens: int, llm: dict) -> bool:
     """Schedule rule of the default (`--overlap -1`) mode: front ends beside the decode only where the decode step is dominated by the
     K / V stream (aurora_amd.streams.overlap_pays at the cycle's mean context; cfg4's 8 slots keep their front ends out of the decode)."""
@@ -642,10 +649,9 @@ def main():
             k_cal["on"] = False
             t_front = float(np.median([a.elapsed_time(b) for a, b in k_cal["front_ev"][:-1]]))      # the last one ran beside nothing (fence)
             t_step = float(np.median([a.elapsed_time(b) / k for a, b, k in k_cal["dec_ev"]]))
-            k_need = int(np.ceil(t_front / max(t_step, 1e-3)))
-            k_cal["info"] = {"front_end_ms_beside_masked_decode": t_front, "masked_decode_step_ms": t_step, "steps_needed": k_need,
-                             "cap_whole_steps_of_a_chunk": k_masked}
-            k_masked = max(1, min(k_masked, k_need))
+            k_cal["info"] = {"front_end_ms_beside_masked_decode": t_front, "masked_decode_step_ms": t_step,
+                             "steps_needed": int(np.ceil(t_front / max(t_step, 1e-3))), "cap_whole_steps_of_a_chunk": k_masked}
+            k_masked = masked_steps_per_chunk(t_front, t_step, k_masked)
             k_cal["front_ev"].clear()
             k_cal["dec_ev"].clear()
         sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None

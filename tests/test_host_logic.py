@@ -224,3 +224,14 @@ def test_bench_schedule_rule_overlaps_only_kv_dominated_decodes():
     llm = S.VICUNA_7B_16K
     assert bench.overlap_pays(128, 2142, 256, llm) and bench.overlap_pays(96, 2766, 512, llm) and bench.overlap_pays(48, 4870, 2048, llm)
     assert not bench.overlap_pays(8, 2142, 256, llm) and not bench.overlap_pays(1, 2142, 256, llm)
+
+
+def test_bench_masked_steps_follow_the_front_end():
+    """The overlapped schedule masks the decode for as many steps of a chunk as the front end lasts beside them (cfg3: 376 ms / 34.9 ms
+    -> 11 of 21; cfg5: 571 / 30.1 -> 19 of 170), never more than the chunk's whole steps (default config: 274 / 37.8 -> 8 needed,
+    7 available) and never none."""
+    import bench
+    assert bench.masked_steps_per_chunk(376.1, 34.9, 21) == 11
+    assert bench.masked_steps_per_chunk(570.9, 30.07, 170) == 19
+    assert bench.masked_steps_per_chunk(273.8, 37.8, 7) == 7
+    assert bench.masked_steps_per_chunk(5.0, 40.0, 7) == 1 and bench.masked_steps_per_chunk(0.0, 0.0, 3) == 1
