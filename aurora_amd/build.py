@@ -1,6 +1,10 @@
 """Build libaurora_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m aurora_amd.build [--force]
+    python -m aurora_amd.build [--force] [--labs | --sanitize | --ubsan]
+
+--labs builds libaurora_hip_labs.so with -DAUR_LABS: the product sources plus the lab-only kernel variants (gemm256.hip G2Lab, the
+round-3 inline-asm split-K hand-over) that tools/cumask/*_lab.py and tools/gpu/soak_fused_reduce.sh select through AURORA_HIP_SO.
+The product library contains none of them.
 
 The shared library has a plain C ABI (include/aurora_hip.h) and no torch / python dependency.
 """
@@ -31,11 +35,12 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(OUT):
+def needs_build(out: str = OUT) -> bool:
+    """stale when any kernel source, the ABI header or this script (the flags) is newer than `out`"""
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "aurora_hip.h")]
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "aurora_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,6 +49,7 @@ def needs_build() -> bool:
 # the shared ASan runtime so that an un-instrumented python can load it with LD_PRELOAD=<asan_runtime()>.  tests/test_asan_host.py.
 OUT_ASAN = os.path.join(HERE, "libaurora_hip_asan.so")
 OUT_UBSAN = os.path.join(HERE, "libaurora_hip_ubsan.so")        # UBSan alone: no preload, coexists with the HIP runtime on a GPU box
+OUT_LABS = os.path.join(HERE, "libaurora_hip_labs.so")          # -DAUR_LABS: lab kernel variants for tools/ only
 SAN = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
 SAN_UB = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
 
@@ -58,19 +64,18 @@ def asan_runtime(name: str = "asan") -> str:
 
 
 def build(force: bool = False, verbose: bool = True, sanitize=False) -> str:
-    """sanitize: False (the product), True / "asan" (ASan + UBSan on the host code), "ubsan" (UBSan only, traps made fatal)"""
+    """sanitize: False (the product), True / "asan" (ASan + UBSan on the host code), "ubsan" (UBSan only, traps made fatal),
+    "labs" (the product flags + -DAUR_LABS)"""
     ub = sanitize == "ubsan"
-    out = OUT_UBSAN if ub else (OUT_ASAN if sanitize else OUT)
-    san = SAN_UB if ub else SAN
-    if sanitize:
-        if not force and os.path.exists(out) and all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(out) for f in os.listdir(CSRC)):
-            return out
-    elif not force and not needs_build():
-        return OUT
+    labs = sanitize == "labs"
+    out = OUT_LABS if labs else OUT_UBSAN if ub else (OUT_ASAN if sanitize else OUT)
+    san = [] if labs else SAN_UB if ub else SAN
+    if not force and not needs_build(out):
+        return out
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, ("build_ubsan" if ub else "build_asan") if sanitize else "build")
+    objdir = os.path.join(HERE, "build_labs" if labs else ("build_ubsan" if ub else "build_asan") if sanitize else "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [c if c != "-O3" else "-O1" for c in COMMON] + san if sanitize else COMMON
+    common = COMMON + ["-DAUR_LABS"] if labs else [c if c != "-O3" else "-O1" for c in COMMON] + san if sanitize else COMMON
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -94,4 +99,4 @@ def build(force: bool = False, verbose: bool = True, sanitize=False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, sanitize="ubsan" if "--ubsan" in sys.argv else ("--sanitize" in sys.argv))
+    build(force="--force" in sys.argv, sanitize="labs" if "--labs" in sys.argv else "ubsan" if "--ubsan" in sys.argv else ("--sanitize" in sys.argv))

@@ -359,7 +359,40 @@ struct SkxGeom {
     int v_tile0;            // SK_QKV: first V tile (= (q_cols + k_cols) / 16)
     int S;                  // k splits (gridDim.y); > 1 only for SK_ROW
     float* part;            // SK_ROW split-K partials, lane-linear [S][N16][NB][64][4]
+    int* cnt;               // SK_ROW: arrival counter per tile (fused reduce), nullptr = skinny_row_reduce_kernel follows
+    int handover;           // AUR_LABS builds only: 2 = the round-3 inline-asm partial stores (soak script)
 };
+
+// 16-byte agent-scope accesses of the split-K hand-over (a tile's S workgroups may sit on different XCDs, whose L2s are not coherent for
+// plain accesses): write-through `sc1` stores, L1-bypassing `sc1` loads - the guide's "sc1 payload -> drained vmcnt -> relaxed agent
+// fetch_add, sc1 loads on the reducer" form of the in-launch split-K reduction.  Both go through the raw-buffer BUILTINS (aux 16 = sc1),
+// i.e. they are instructions hipcc knows: it counts them in vmcnt and pads their hazards.
+//
+// Round 3 wrote the partials with inline asm (`global_store_dwordx4 .. sc1`) and was caught producing different captions in one serving
+// run of three.  Root cause (profiles/r04_fused_reduce_rootcause.txt): hipcc treats an asm statement as one opaque
+// instruction and does not pad its hazards, and gfx950 requires wait states between a VMEM store of more than 64 bits and a VALU write of
+// the store's DATA registers.  The NB >= 4 instantiations came out as
+//     global_store_dwordx4 v[18:19], v[10:13], off sc1 ; s_mov_b64 s[0:1], 0x400 ; v_lshl_add_u64 v[10:11], v[18:19], 0, s[0:1]
+// - the next store's address computed INTO the previous store's data registers one state later.  Alone the store unit has read its data by
+// then; with the memory pipeline backed up beside a front end it sometimes has not, and a partial goes out with two dwords of an
+// address in it.  The protocol (counter, sc1, drain) was sound.  AUR_LABS builds keep that form as hand-over 2 for the soak script.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the split-K hand-over relies on gfx950 sc1 semantics"
+#endif
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(float* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);       // raw buffer: byte offsets, bounds-checked against `bytes`
+}
+__device__ __forceinline__ void st_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const f4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ f4 ld_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+#ifdef AUR_LABS
+// the round-3 form, kept for tools/gpu/soak_fused_reduce.sh only: no wait state after the store (see above)
+__device__ __forceinline__ void st_agent16_r03(float* p, const f4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+#endif
 
 template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
 __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(SkinnyArgs a, SkxGeom gm) {
@@ -508,7 +541,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
         SKX_BAR();
         if (!epi_wave && !split) return;
-        if (split && p != 0) return;
+        if (split && gm.cnt == nullptr && p != 0) return;
         // column groups [g0, g0 + cnt) of the tile whose first wave is w0
         auto gather = [&](int w0, int g0, auto& dst) {
             constexpr int cnt = sizeof(dst) / sizeof(f4);
@@ -544,6 +577,69 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
             return;
         }
         f4 one[1][NBPV];
+        if constexpr (MODE == SK_ROW) {
+            if (split && gm.cnt != nullptr) {
+                // ---- split-K with the reduce IN the kernel: k split s publishes its partial tile (agent scope), counts itself in, and
+                // the split that finds the tile complete sums the S = 4 partials in the fixed order s = 0, 1, 2, 3 and runs the residual
+                // epilogue - exactly the arithmetic of skinny_row_reduce_kernel (bitwise), without its launch.  The tail is shared by the
+                // tile's KS waves (column groups p, p + KS, ..).  A tile's 4 splits are workgroups c, c + gridDim.x, ..: the same XCD when
+                // gridDim.x % 8 == 0, so in practice the partials are L2 hits; correctness does not rely on it.
+                int* last_lds = (int*)(rstd_lds + AUR_MAX_BATCH);               // [T_MAX]
+                const __amdgpu_buffer_rsrc_t prs = part_rsrc(gm.part, gm.S * N16 * NB * 1024);
+                if (p == 0) {
+                    gather(t * KS, 0, one[0]);
+                    const unsigned off0 = (unsigned)((((s * N16 + tile) * NB) * 64 + lane) * 16);
+#ifdef AUR_LABS
+                    if (gm.handover == 2) {
+#pragma unroll
+                        for (int nb = 0; nb < NBPV; ++nb) st_agent16_r03(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4, one[0][nb]);
+                    } else
+#endif
+                    {
+#pragma unroll
+                        for (int nb = 0; nb < NBPV; ++nb) st_agent16(prs, off0 + nb * 1024, one[0][nb]);
+                    }
+                    // the partial has reached the coherence point before the arrival is counted.  An asm wait on purpose: hipcc may
+                    // drop its own vmcnt(0) ahead of an atomic when its scoreboard is empty (guide, Guideline 16 pitfall 12)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+                        const int arrived = __hip_atomic_fetch_add(gm.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int last = arrived == gm.S - 1;
+                        if (last) __hip_atomic_store(gm.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+                        last_lds[t] = last;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                SKX_BAR();
+                if (!last_lds[t]) return;
+                constexpr int GPW = (NB + KS - 1) / KS;                          // column groups per wave of the tail
+                f4 q[GPW][4];
+                const unsigned sstride = (unsigned)(N16 * NB * 1024);
+#pragma unroll
+                for (int i = 0; i < GPW; ++i) {
+                    int nb = p + i * KS;
+                    nb = nb < NB ? nb : NB - 1;
+                    const unsigned off = (unsigned)(((tile * NB + nb) * 64 + lane) * 16);
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) q[i][ss] = ld_agent16(prs, off + ss * sstride);
+                }
+#pragma unroll
+                for (int i = 0; i < GPW; ++i) {
+                    const int nb = p + i * KS;
+                    if (nb >= NB) continue;
+                    SkPre<1> pre1;
+                    skinny_prefetch<SK_ROW, 1>(a, lane, pre1, tile, nb);
+                    f4 acc1[1][1];
+                    acc1[0][0] = q[i][0];
+#pragma unroll
+                    for (int ss = 1; ss < 4; ++ss)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc1[0][0][e] += q[i][ss][e];
+                    skinny_store<1, SK_ROW, 1>(a, tile, acc1, lane, pre1, nb);
+                }
+                return;
+            }
+        }
         gather(t * KS, eg0, one[0]);
         if (split) {                                           // split-K partial, lane-linear: one 16-byte store per lane and column group
 #pragma unroll
@@ -593,7 +689,7 @@ static int g_skx_cus = 256;
 template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
 static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid, hipStream_t s) {
     constexpr int ring = NBUF * KC * NB * 1024;
-    constexpr int lds = ring + AUR_MAX_BATCH * 4;              // + 1/rms per batch row
+    constexpr int lds = ring + AUR_MAX_BATCH * 4 + 64;         // + 1/rms per batch row + the fused split-K reduce's "last split" flags
     static_assert(ring >= T_MAX * KS * NB * 1024, "the reduction scratch lives inside the x ring");
     static bool attr_set = false;
     if (!attr_set) {
@@ -664,8 +760,10 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             // (round 3 re-swept this geometry in tools/gemv_lab, profiles/r03_gemv_lab_row.log: 2 k phases over chunks of 8 k32 is 1-2 us faster
             // there, o 18.9 -> 18.0 us, down 31.5 -> 29.4 us incl. the reduce, but neutral in the engine - 19.3 / 30.1 us either way - and
             // rocprofv3's counter mode crashed in this launch with that instantiation: kept as it was)
+            gm.cnt = a.row_cnt;
+            gm.handover = a.row_handover;
             hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess || gm.cnt != nullptr) return e;
             hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);
             return hipGetLastError();
         }

@@ -76,6 +76,8 @@ struct aur_ctx {
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
+    int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
+    int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
     // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
@@ -261,6 +263,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_h = k.take<half_t>(Bp * g.llm_mlp);               // SiLU(gate)*up     (x-fragment form)
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
+    c->d_row_cnt = k.take<int>(c->l_dpad / 16);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
@@ -338,6 +341,7 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     ctx->finalized = false;
     // arrival counters of the ToMe match + select launch: zero now, and every launch leaves them at zero
     if (ctx->w_tome_cnt) CK(hipMemset(ctx->w_tome_cnt, 0, (size_t)ctx->cfg.max_frames * 4));
+    if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -1056,6 +1060,7 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
     o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
     o.variant = ctx->skinny_variant; o.part = (d >= ctx->row_split_min_k || ctx->cfg.max_batch > 64) ? ctx->d_part_row : nullptr;
+    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; o.row_handover = ctx->fused_reduce;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -1075,6 +1080,7 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
     dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
     dn.variant = ctx->skinny_variant; dn.part = (g.llm_mlp >= ctx->row_split_min_k || g.max_batch > 64) ? ctx->d_part_row : nullptr;
+    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; dn.row_handover = ctx->fused_reduce;
     return dn;
 }
 
@@ -1166,9 +1172,7 @@ extern "C" int aur_slot_reset(aur_ctx* ctx, int32_t slot, void* stream) {
 }
 extern "C" int aur_slot_retire(aur_ctx* ctx, int32_t slot, void* stream) {
     if (int rc = slot_check(ctx, slot, "aur_slot_retire")) return rc;
-    const int32_t one = 1;
-    CK(hipMemcpyAsync(ctx->s_fin + slot, &one, 4, hipMemcpyHostToDevice, (hipStream_t)stream));
-    CK(hipStreamSynchronize((hipStream_t)stream));          // `one` lives on this stack frame
+    CK(hipMemsetD32Async((hipDeviceptr_t)(ctx->s_fin + slot), 1, 1, (hipStream_t)stream));      // a fill node: no host source, no synchronisation
     return AUR_OK;
 }
 extern "C" int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, void* stream) {
@@ -1212,7 +1216,13 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
         else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value >= 0 && value <= 2) ? (int)value : 1;
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
-        else if (!strcmp(name, "gemm_lab")) ctx->gemm_lab = (value >= 0 && value <= 7) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only
+        else if (!strcmp(name, "gemm_lab")) {
+#ifdef AUR_LABS
+            ctx->gemm_lab = (value >= 0 && value <= 7) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
+#else
+            return aur_fail(ctx, AUR_ERR_ARG, "gemm_lab exists in AUR_LABS builds only (python -m aurora_amd.build --labs)");
+#endif
+        }
         else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
         else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
         return AUR_OK;
@@ -1221,6 +1231,16 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
+    } else if (!strcmp(name, "decode_fused_reduce")) {
+        // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (the last-arriving split reduces;
+        // decode.hip "split-K with the reduce IN the kernel"); 0: a second launch does (skinny_row_reduce_kernel).  Bitwise the same tokens.
+        // 2 exists in AUR_LABS builds only: round 3's hazard-prone inline-asm partial stores, for tools/gpu/soak_fused_reduce.sh.
+#ifdef AUR_LABS
+        if (value < 0 || value > 2) return aur_fail(ctx, AUR_ERR_ARG, "decode_fused_reduce must be 0, 1 or 2 (lab)");
+#else
+        if (value < 0 || value > 1) return aur_fail(ctx, AUR_ERR_ARG, "decode_fused_reduce must be 0 or 1");
+#endif
+        ctx->fused_reduce = (int)value;
     } else if (!strcmp(name, "decode_half_grid")) {
         // the following aur_llm_decode calls go to a stream that owns half of the CUs: QKV / gate-up launch half as many workgroups
         // with twice the tiles (decode.hip launch_skx_nb); bitwise the same tokens.  Keeps both captured graphs.

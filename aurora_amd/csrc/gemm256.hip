@@ -27,8 +27,14 @@
 // TAG >= GT_LAB_BASE selects a deliberately altered kernel that answers "what does the front-end GEMM take away from a concurrent
 // decode stream?": cache-policy bits on the operand DMAs, no DMA at all (power / clock only), no MFMA (fabric traffic only), or the
 // activation operand read from a K-tile-major image (DRAM-friendly 32 KiB blocks instead of 128-byte row pieces; results are garbage).
+// Compiled only with -DAUR_LABS (python -m aurora_amd.build --labs -> libaurora_hip_labs.so); the product library carries G2Lab<..>::id == 0 only.
 template <int TAG> struct G2Lab {
+#ifdef AUR_LABS
     static constexpr int id = TAG >= GT_LAB_BASE ? TAG - GT_LAB_BASE : 0;
+#else
+    static_assert(TAG < GT_LAB_BASE, "lab instantiations need -DAUR_LABS");
+    static constexpr int id = 0;
+#endif
     static constexpr int aux_a = (id == 1 || id == 3) ? 2 : (id == 4 ? 16 : 0);     // 2 = nt, 16 = sc1
     static constexpr int aux_w = (id == 2 || id == 3) ? 2 : (id == 4 ? 16 : 0);
     static constexpr bool no_dma = id == 5;
@@ -372,11 +378,13 @@ hipError_t gemm256_init() {
         (e = g2_attr<EPI_ROW, GT_LLM_DOWN>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_OTHER>()) != hipSuccess ||
         (e = g2_attr<EPI_QKV, GT_VIT_QKV>()) != hipSuccess || (e = g2_attr<EPI_QKV, GT_LLM_QKV>()) != hipSuccess)
         return e;
+#ifdef AUR_LABS
     if ((e = g2_attr<EPI_ROW, GT_LAB_BASE + 1>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 2>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 3>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 4>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 5>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 6>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess)
         return e;
+#endif
     return hipSuccess;
 }
 
@@ -396,6 +404,9 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     dim3 grid(ntiles), block(512);
 #define G2_LAUNCH(E, T) hipLaunchKernelGGL((gemm256_kernel<E, T>), grid, block, G2_LDS, s, a)
     if (epi == EPI_ROW && a.lab > 0) {            // lab instantiations only (contention_lab.py)
+#ifndef AUR_LABS
+        return hipErrorInvalidValue;
+#else
         switch (a.lab) {
             case 1: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 1); break;
             case 2: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 2); break;
@@ -406,6 +417,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 7: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 7); break;
             default: return hipErrorInvalidValue;
         }
+#endif
     } else if (epi == EPI_ROW) {
         switch (a.tag) {
             case GT_VIT_OUT: G2_LAUNCH(EPI_ROW, GT_VIT_OUT); break;

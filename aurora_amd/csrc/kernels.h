@@ -150,6 +150,10 @@ struct SkinnyArgs {
     int variant;
     int ring;               // variant 1, > 64 rows: 0 = 4 x (4 k32) x-ring buffers, 1 = 2 x (8 k32): fewer barriers, measured 52.4 vs 55.8 us (QKV) and 46.2 vs 49.7 us (gate/up) at 128 rows
     float* part;            // variant 1, SK_ROW: split-K partials [4][Npad/16][ceil(B/16)][64][4] fp32 (nullptr: keep structure 0)
+    int* row_cnt;           // variant 1, SK_ROW: arrival counters [Npad/16], zero between launches: the workgroup that completes a tile's 4
+                            // partials sums them (fixed order) and runs the residual epilogue IN the projection kernel.  nullptr = a second
+                            // launch does it (skinny_row_reduce_kernel; bitwise the same result)
+    int row_handover;       // AUR_LABS builds only: 2 = the partials go out through round 3's inline-asm stores (tools/gpu/soak_fused_reduce.sh)
     int gu_ks;              // variant 1, SK_SILU_MUL: k phases per tile, 2 (default) or 1 (engines of > 64 slots: the half grid needs it).
                             // A constant of the ENGINE: it fixes the summation order
     int half_grid;          // variant 1, > 64 rows, SK_QKV / SK_SILU_MUL: 1 = half as many workgroups with twice the tiles each, for

@@ -99,6 +99,8 @@ def parse():
     p.add_argument("--dec-attn-variant", type=int, default=-1, help="A/B: decode attention kernel (1 MFMA page pipeline, 3 the same with two waves per SIMD, 4 VALU dot products)")
     p.add_argument("--prune-last", type=int, default=-1, help="A/B: 0 = the last prefill layer computes every row (as HF does), 1 (engine default) = K / V for every "
                    "row, the rest for each sequence's last 128 rows only (bitwise the same outputs)")
+    p.add_argument("--fused-reduce", type=int, default=-1, help="A/B: 0 (engine default) = the split-K residual projections (o, down) are followed by a reduce launch, 1 = "
+                   "the reduce runs inside the projection kernel (bitwise the same outputs; measured no faster)")
     p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
                                                             "launches short - rocprofv3's counter mode crashed with ~11 k launches queued ahead of the GPU)")
     p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "
@@ -363,6 +365,8 @@ def main():
         eng.set_option("dec_attn_variant", args.dec_attn_variant)
     if args.prune_last >= 0:
         eng.set_option("prefill_prune_last", args.prune_last)
+    if args.fused_reduce >= 0:
+        eng.set_option("decode_fused_reduce", args.fused_reduce)
 
     # synthetic inputs, resident in HBM before the timed region
     clip0 = rank * B

@@ -130,3 +130,40 @@ def test_half_grid_decode_is_bitwise_the_full_grid_decode(B):
         assert torch.equal(eng.logits(), lg_full)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("B,name", [(40, "hd64"), (70, "hd128"), (128, "hd64")])
+def test_fused_split_k_reduce_is_bitwise_the_two_launch_form(B, name):
+    """`decode_fused_reduce` (built for VERDICT r2 item 2; measured no faster, so the default stays the two-launch form): the split-K residual projections (o, down) sum their 4 partials INSIDE the projection
+    kernel - the split that finds a tile complete (agent-scope arrival counter, sc1 partials) adds them in the fixed order
+    s = 0..3 and runs the residual / sum(x^2) epilogue - instead of a second launch (`skinny_row_reduce_kernel`).  Same
+    additions in the same order: tokens and logits bit for bit, eager and as a hipGraph; repeated runs identical (a lost or
+    early hand-over would show as a different sum) with a second stream keeping the GPU busy, as in the serving schedule; and
+    the arrival counters are back at zero after every launch (the next launch - or graph replay - relies on it)."""
+    cfg = LLM_CFGS[name]
+    gen = torch.Generator().manual_seed(300 + B)
+    lens = [33 + (5 * i) % 70 for i in range(B)]
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
+    res = {}
+    for use_graph in (False, True):
+        eng, w = lds_engine(cfg, 9, B, use_graph=use_graph)
+        try:
+            for fused in (0, 1, 1):
+                eng.set_option("decode_fused_reduce", fused)
+                side = torch.cuda.Stream()
+                noise = torch.randn(4096, 4096, device="cuda")
+                with torch.cuda.stream(side):                      # a busy neighbour: uneven arrival of the splits
+                    for _ in range(20):
+                        noise = noise @ noise * 1e-4
+                ids = eng.generate([padded(e) for e in embs], lens, 12, eos_id=None)
+                cur = (ids, eng.logits().clone())
+                side.synchronize()
+                if (use_graph, fused) in res:
+                    assert cur[0] == res[(use_graph, fused)][0] and torch.equal(cur[1], res[(use_graph, fused)][1])
+                res[(use_graph, fused)] = cur
+        finally:
+            eng.close()
+    base = res[(False, 0)]
+    for key, cur in res.items():
+        assert cur[0] == base[0], key
+        assert torch.equal(cur[1], base[1]), key
