@@ -14,6 +14,12 @@ SO_PATH = os.environ.get("AURORA_HIP_SO") or os.path.join(HERE, "libaurora_hip.s
 
 AUR_ACT_QUICK_GELU = 1
 AUR_ACT_GELU = 2
+AUR_ACT_SILU = 4
+AUR_ACT_RELU = 5
+AUR_ACT_GELU_TANH = 6
+# transformers' ACT2FN names (modeling_projector.py:27 `ACT2FN[config.hidden_act]`) the kernels' epilogues implement; anything else raises
+ACT_BY_NAME = {"quick_gelu": AUR_ACT_QUICK_GELU, "gelu": AUR_ACT_GELU, "silu": AUR_ACT_SILU, "swish": AUR_ACT_SILU, "relu": AUR_ACT_RELU,
+               "gelu_new": AUR_ACT_GELU_TANH, "gelu_pytorch_tanh": AUR_ACT_GELU_TANH}
 
 
 class AurConfig(C.Structure):
@@ -26,7 +32,7 @@ class AurConfig(C.Structure):
         ("llm_rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_factor", C.c_float),
         ("max_frames", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32),
         ("page_tokens", C.c_int32), ("use_graph", C.c_int32), ("num_banks", C.c_int32), ("vit_native_image", C.c_int32),
-        ("spare_slots", C.c_int32),
+        ("spare_slots", C.c_int32), ("proj_depth", C.c_int32), ("proj_act", C.c_int32),
     ]
 
 

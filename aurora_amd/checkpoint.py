@@ -80,6 +80,27 @@ def llm_config(d: str) -> dict:
                 eos_token_id=c.get("eos_token_id", 2), bos_token_id=c.get("bos_token_id", 1))
 
 
+def projector_config(d: str) -> dict:
+    """projector/config.json as the reference's `ProjectorConfig` reads it (configuration_projector.py:9-22): absent keys take the
+    class defaults.  `ProjectorModel.__init__` (modeling_projector.py:20-33) builds `depth` Linear layers with `ACT2FN[hidden_act]`
+    between them and an optional bias - all three are honoured by the engine or rejected loudly (aurora_amd.engine.projector_settings)."""
+    p = os.path.join(d, "config.json")
+    c = _json(p) if os.path.exists(p) else {}
+    return dict(visual_hidden_size=c.get("visual_hidden_size", 4096), llm_hidden_size=c.get("llm_hidden_size", 4096),
+                depth=c.get("depth", 2), hidden_act=c.get("hidden_act", "gelu"), bias=c.get("bias", True))
+
+
+def projector_weights(sd: Dict[str, torch.Tensor], pcfg: dict) -> dict:
+    """`model.0`, `model.2`, .. `model.{2 (depth - 1)}` (the odd positions of the nn.Sequential are the activations); every key the
+    config implies must be there and nothing else"""
+    want = [f"model.{2 * i}.{n}" for i in range(int(pcfg["depth"])) for n in (("weight", "bias") if pcfg["bias"] else ("weight",))]
+    missing = [k for k in want if k not in sd]
+    extra = [k for k in sd if k.startswith("model.") and k not in want]
+    if missing or extra:
+        raise KeyError(f"projector checkpoint does not match its config (depth {pcfg['depth']}, bias {pcfg['bias']}): missing {missing}, unexpected {extra}")
+    return {k: sd[k] for k in want}
+
+
 def vit_weights(sd: Dict[str, torch.Tensor], cfg: dict) -> dict:
     p = "vision_model."
     if not any(k.startswith(p) for k in sd):
@@ -124,8 +145,10 @@ def load_auroracap(root: str, visual_encoder: str = "visual_encoder", projector:
     for d in (root, vdir, pdir):
         if not os.path.isdir(d):
             raise FileNotFoundError(f"{d} is not a directory (expected <root>/, <root>/visual_encoder, <root>/projector)")
-    cfg = {"vit": vit_config(vdir), "llm": llm_config(root)}
-    psd = _load_state(pdir)
+    cfg = {"vit": vit_config(vdir), "llm": llm_config(root), "projector": projector_config(pdir)}
+    for key, have in (("visual_hidden_size", cfg["vit"]["hidden_size"]), ("llm_hidden_size", cfg["llm"]["hidden_size"])):
+        if cfg["projector"][key] != have:
+            raise ValueError(f"projector/config.json {key} = {cfg['projector'][key]} but the loaded model has {have}")
     weights = {"vit": vit_weights(_load_state(vdir), cfg["vit"]), "llm": llm_weights(_load_state(root), cfg["llm"]),
-               "projector": {k: psd[k] for k in ("model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias")}}
+               "projector": projector_weights(_load_state(pdir), cfg["projector"])}
     return cfg, weights

@@ -90,6 +90,13 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float quick_gelu_f(float x) { return __fdividef(x, 1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+// the activations a ProjectorConfig.hidden_act may name besides the two above (act = ACT_SILU / ACT_RELU / ACT_GELU_TANH, kernels.h); one
+// uniform branch per element behind the two common cases, never on the ViT / Llama path
+__device__ __forceinline__ float act_other_f(float x, int act) {
+    if (act == 4) return silu_f(x);
+    if (act == 5) return fmaxf(x, 0.f);
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
 
 // PAIRED k-slot helpers: position of element k (0..31) inside a fragment lane group.
 __device__ __host__ __forceinline__ int paired_g(int k) { return (k & 15) >> 2; }

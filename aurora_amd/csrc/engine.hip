@@ -55,8 +55,11 @@ struct aur_ctx {
     // weights
     std::vector<VitLayerW> vl;
     std::vector<LlmLayerW> ll;
-    const half_t *v_patch_w, *v_cls, *v_pos, *p_fc1_w, *p_fc2_w, *l_embed, *l_head_w;
-    const float *v_preln_w, *v_preln_b, *p_fc1_b, *p_fc2_b, *l_norm_w;
+    const half_t *v_patch_w, *v_cls, *v_pos, *l_embed, *l_head_w;
+    const float *v_preln_w, *v_preln_b, *l_norm_w;
+    std::vector<const half_t*> p_w;      // projector Linear layers (modeling_projector.py:20-33): [proj_depth] packed weights
+    std::vector<const float*> p_b;       //                                                        and biases (zeros for bias = False)
+    int p_depth = 2, p_act = ACT_GELU;
     // workspace regions (vision)
     half_t *w_col, *w_patch, *w_xa, *w_xb, *w_xn, *w_qf, *w_kv, *w_attn, *w_h;
     float *w_metric, *w_mhat, *w_nmax, *w_sza, *w_szb;
@@ -295,8 +298,14 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
             (e = skinny_init()) != hipSuccess || (e = gemm256_init()) != hipSuccess)
             return aur_fail(nullptr, AUR_ERR_HIP, "kernel attribute init failed (is a gfx950 GPU visible?): %s", hipGetErrorString(e));
     }
+    if (g.proj_depth < 0 || g.proj_depth > 8) return aur_fail(nullptr, AUR_ERR_ARG, "proj_depth must be 0 (= 2) or 1 .. 8");
+    if (g.proj_act != 0 && g.proj_act != AUR_ACT_QUICK_GELU && g.proj_act != AUR_ACT_GELU && g.proj_act != AUR_ACT_SILU && g.proj_act != AUR_ACT_RELU &&
+        g.proj_act != AUR_ACT_GELU_TANH)
+        return aur_fail(nullptr, AUR_ERR_UNSUPPORTED, "proj_act %d is not one of AUR_ACT_*", g.proj_act);
     aur_ctx* c = new aur_ctx();
     c->cfg = g;
+    c->p_depth = g.proj_depth > 0 ? g.proj_depth : 2;
+    c->p_act = g.proj_act > 0 ? g.proj_act : ACT_GELU;
     derive(c);
     *out = c;
     return AUR_OK;
@@ -410,12 +419,18 @@ extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
             if (!ok) return AUR_ERR_STATE;
         }
         // projector is part of the language-side prefix path
-        if (ctx->tensors.count("proj.fc1.w")) {
-            ok = get(ctx, "proj.fc1.w", &ctx->p_fc1_w, (int64_t)ctx->l_dpad * g.vit_hidden * 2) && get(ctx, "proj.fc1.b", &ctx->p_fc1_b, (int64_t)ctx->l_dpad * 4) &&
-                 get(ctx, "proj.fc2.w", &ctx->p_fc2_w, (int64_t)ctx->l_dpad * d * 2) && get(ctx, "proj.fc2.b", &ctx->p_fc2_b, (int64_t)ctx->l_dpad * 4);
-            if (!ok) return AUR_ERR_STATE;
-        } else {
-            ctx->p_fc1_w = nullptr;
+        ctx->p_w.clear();
+        ctx->p_b.clear();
+        if (ctx->tensors.count("proj.0.w")) {
+            for (int i = 0; i < ctx->p_depth; ++i) {
+                const half_t* pw;
+                const float* pb;
+                const std::string p = "proj." + std::to_string(i) + ".";
+                ok = get(ctx, p + "w", &pw, (int64_t)ctx->l_dpad * (i == 0 ? g.vit_hidden : d) * 2) && get(ctx, p + "b", &pb, (int64_t)ctx->l_dpad * 4);
+                if (!ok) return AUR_ERR_STATE;
+                ctx->p_w.push_back(pw);
+                ctx->p_b.push_back(pb);
+            }
         }
         // RoPE table (HF linear scaling: position / factor), cos/sin in fp32 like HF
         const int half = ctx->l_hd / 2;
@@ -766,7 +781,7 @@ extern "C" int aur_rmsnorm(aur_ctx* ctx, const void* x, int32_t rows, int32_t d,
 // ------------------------------------------------------------------------------------------ projector + splice
 extern "C" int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, const int32_t* vis_rows, const int32_t* text_ids,
                                   const int32_t* text_rows, int32_t ntext, int32_t seq_len, void* embeds, void* stream) {
-    if (!ctx->finalized || !ctx->p_fc1_w) return aur_fail(ctx, AUR_ERR_STATE, "aur_project_splice: projector weights not finalized");
+    if (!ctx->finalized || ctx->p_w.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_project_splice: projector weights not finalized");
     const aur_config& g = ctx->cfg;
     if (seq_len < 1 || seq_len > g.max_ctx || nvis + ntext != seq_len) return aur_fail(ctx, AUR_ERR_ARG, "aur_project_splice: seq_len %d (nvis %d + ntext %d), max_ctx %d", seq_len, nvis, ntext, g.max_ctx);
     hipStream_t s = (hipStream_t)stream;
@@ -774,14 +789,21 @@ extern "C" int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, c
     const int d = g.llm_hidden, lp = rup(seq_len, 32);
     if (lp > seq_len) CK(hipMemsetAsync((half_t*)embeds + (int64_t)seq_len * d, 0, (size_t)(lp - seq_len) * d * 2, s));
     if (nvis > 0) {
-        GemmArgs a{};
-        a.A = (const half_t*)vis; a.lda = g.vit_hidden; a.W = ctx->p_fc1_w; a.bias = ctx->p_fc1_b; a.M = nvis; a.Npad = ctx->l_dpad;
-        a.K = g.vit_hidden; a.C = ctx->l_p1; a.ldc = d; a.n_real = d; a.act = ACT_GELU;
-        CK(ctx_gemm(ctx, a, EPI_ROW, s));                                   // modeling_projector.py:20-33 (erf GELU)
-        GemmArgs b{};
-        b.A = ctx->l_p1; b.lda = d; b.W = ctx->p_fc2_w; b.bias = ctx->p_fc2_b; b.M = nvis; b.Npad = ctx->l_dpad; b.K = d;
-        b.C = (half_t*)embeds; b.ldc = d; b.n_real = d; b.act = ACT_NONE; b.out_rows = vis_rows;
-        CK(ctx_gemm(ctx, b, EPI_ROW, s));                                   // written straight into the spliced rows
+        // modeling_projector.py:20-33: Linear, then (act, Linear) x (depth - 1); the activation rides in the producing GEMM's epilogue and
+        // the LAST Linear writes straight into the spliced rows.  Intermediates ping-pong between l_p1 and l_xn (front-end scratch, free
+        // until the prefill that follows on this stream).
+        const half_t* in = (const half_t*)vis;
+        int K = g.vit_hidden;
+        for (int i = 0; i < ctx->p_depth; ++i) {
+            const bool last = i == ctx->p_depth - 1;
+            half_t* out = last ? (half_t*)embeds : ((i & 1) ? ctx->l_xn : ctx->l_p1);
+            GemmArgs a{};
+            a.A = in; a.lda = K; a.W = ctx->p_w[i]; a.bias = ctx->p_b[i]; a.M = nvis; a.Npad = ctx->l_dpad; a.K = K;
+            a.C = out; a.ldc = d; a.n_real = d; a.act = last ? ACT_NONE : ctx->p_act; a.out_rows = last ? vis_rows : nullptr;
+            CK(ctx_gemm(ctx, a, EPI_ROW, s));
+            in = out;
+            K = d;
+        }
     }
     CK(launch_embed_rows(ctx->l_embed, d, text_ids, text_rows, ntext, (half_t*)embeds, d, s));   // utils.py:214-216
     stage_end(ctx, "project", s);

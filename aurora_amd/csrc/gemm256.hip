@@ -251,6 +251,9 @@ __device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][
             } else if (a.act == ACT_GELU) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+            } else if (a.act >= ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
             }
             *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
         }

@@ -35,6 +35,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
                     } else if (a.act == ACT_GELU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+                    } else if (a.act >= ACT_SILU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
                     }
                     if (a.resid) {
                         const h4 rr = *(const h4*)(a.resid + (int64_t)m * a.ldr + n);

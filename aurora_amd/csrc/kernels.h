@@ -3,7 +3,7 @@
 #include "common.h"
 
 enum { EPI_ROW = 0, EPI_QKV = 1 };
-enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2, ACT_SILU_MUL = 3 };
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU = 2, ACT_SILU_MUL = 3, ACT_SILU = 4, ACT_RELU = 5, ACT_GELU_TANH = 6 };   // 1, 2, 4, 5, 6 = AUR_ACT_*
 
 struct GemmArgs {
     const half_t* A;        // [M, K] row-major activations

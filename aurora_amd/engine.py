@@ -35,6 +35,20 @@ def tokens_at_layer(t0: int, r: int, layer: int) -> int:
     return int(_lib.lib().aur_tokens_at_layer(t0, r, layer))
 
 
+def projector_settings(pc: dict, visual_hidden: Optional[int], llm_hidden: Optional[int]) -> dict:
+    """Validated ProjectorConfig values (configuration_projector.py:9-22; defaults = the class's own: depth 2, 'gelu', bias True).
+    Raises on what the kernels do not implement instead of loading it wrong."""
+    depth, act, bias = int(pc.get("depth", 2)), pc.get("hidden_act", "gelu"), bool(pc.get("bias", True))
+    if not 1 <= depth <= 8:
+        raise NotImplementedError(f"projector depth {depth}: 1 .. 8 Linear layers are supported")
+    if act not in _lib.ACT_BY_NAME:
+        raise NotImplementedError(f"projector hidden_act {act!r}: the GEMM epilogues implement {sorted(_lib.ACT_BY_NAME)}")
+    for key, have in (("visual_hidden_size", visual_hidden), ("llm_hidden_size", llm_hidden)):
+        if key in pc and have is not None and int(pc[key]) != int(have):
+            raise ValueError(f"projector config {key} = {pc[key]} but the {'vision tower' if key[0] == 'v' else 'language model'} has hidden size {have}")
+    return dict(depth=depth, hidden_act=act, bias=bias)
+
+
 class AuroraCapEngine:
     def __init__(self, cfg: dict, weights: dict, *, max_frames: int = 8, max_batch: int = 1, max_ctx: int = 4096,
                  max_new_tokens: int = 256, page_tokens: int = 64, use_graph: bool = True, num_banks: int = 1,
@@ -79,6 +93,13 @@ class AuroraCapEngine:
         c.max_new_tokens, c.page_tokens, c.use_graph = max_new_tokens, page_tokens, int(use_graph)
         c.num_banks = num_banks
         c.spare_slots = spare_slots
+        # projector (configuration_projector.py:9-22): depth / hidden_act / bias come from projector/config.json (cfg["projector"],
+        # aurora_amd.checkpoint.projector_config); without one: the AuroraCap defaults, whose depth is read off the weight keys
+        pc = dict(cfg.get("projector") or {})
+        if "depth" not in pc and "projector" in weights:
+            pc["depth"] = sum(1 for k in weights["projector"] if k.endswith(".weight"))
+        self.proj_cfg = projector_settings(pc, vv["hidden_size"] if v else None, ll["hidden_size"] if l else None)
+        c.proj_depth, c.proj_act = self.proj_cfg["depth"], _lib.ACT_BY_NAME[self.proj_cfg["hidden_act"]]
         self.spare_slots = spare_slots
         self._bank_state = {0: (0, 0), 1: (0, 0)}        # bank -> (batch, max_new) for outputs()
         self._bank = 0
@@ -263,12 +284,23 @@ class AuroraCapEngine:
             self._set(p + "down.w", self.pack(lw["down_proj.weight"], dpad, mlp))
 
     def _load_projector(self, w: dict):
-        d, dv = self.l["hidden_size"], self.v["hidden_size"]
+        """modeling_projector.py:20-33: `model.0`, then (`ACT2FN[hidden_act]`, `model.2k`) for k = 1 .. depth - 1.  A bias-free projector
+        (`bias=False`) loads zeros.  Keys, shapes and count are checked against the config: nothing loads silently wrong."""
+        d, dv, pc = self.l["hidden_size"], self.v["hidden_size"], self.proj_cfg
         dpad = _rup(d, 256)
-        self._set("proj.fc1.w", self.pack(w["model.0.weight"], dpad, dv))
-        self._set("proj.fc1.b", self._bias(w["model.0.bias"], dpad))
-        self._set("proj.fc2.w", self.pack(w["model.2.weight"], dpad, d))
-        self._set("proj.fc2.b", self._bias(w["model.2.bias"], dpad))
+        want = {f"model.{2 * i}.weight" for i in range(pc["depth"])}
+        have = {k for k in w if k.endswith(".weight")}
+        if want != have:
+            raise ValueError(f"projector weights {sorted(have)} do not match depth {pc['depth']} (expected {sorted(want)})")
+        for i in range(pc["depth"]):
+            wt, k_in = w[f"model.{2 * i}.weight"], (dv if i == 0 else d)
+            if tuple(wt.shape) != (d, k_in):
+                raise ValueError(f"projector model.{2 * i}.weight has shape {tuple(wt.shape)}, the configs say {(d, k_in)}")
+            b = w.get(f"model.{2 * i}.bias")
+            if (b is not None) != pc["bias"]:
+                raise ValueError(f"projector model.{2 * i}.bias {'present' if b is not None else 'missing'} but config.bias is {pc['bias']}")
+            self._set(f"proj.{i}.w", self.pack(wt, dpad, k_in))
+            self._set(f"proj.{i}.b", self._bias(b if b is not None else torch.zeros(d), dpad))
 
     # ------------------------------------------------------------------ hot path
     def tome_r(self, token_kept_ratio: float, height: Optional[int] = None, width: Optional[int] = None) -> int:
@@ -609,8 +641,10 @@ class AuroraCapEngine:
                             # on half of the CUs the QKV / gate-up projections launch half as many workgroups with twice the tiles each
                             # (bitwise the same tokens; engines of <= 64 slots ignore it)
                             self.set_option("decode_half_grid", 1)
-                            self.decode(k1)
-                            self.set_option("decode_half_grid", 0)
+                            try:
+                                self.decode(k1)
+                            finally:                                # a failed decode must not leave the ctx replaying the half-grid graph
+                                self.set_option("decode_half_grid", 0)
                         sD.wait_stream(sDm)
                     if check_every - k1 > 0:
                         self.decode(check_every - k1)

@@ -218,28 +218,65 @@ def cpu_baseline(cfg, args, n_kept):
 
 
 class PowerSampler:
-    """Socket power and shader clock of this rank's GPU during the timed region (`rocm-smi`, one sample per ~1.5 s from a helper
-    thread; rank 0 only).  Round 3 found the overlapped schedule running AT the 1400 W socket cap with sclk ~2.1 GHz:
-    the line carries the evidence.  Any failure (no rocm-smi, unknown json keys) just leaves the fields out."""
+    """Socket power and shader clock of this rank's GPU during the timed region (rank 0 only).  Round 3 found the overlapped schedule
+    running AT the 1400 W socket cap with sclk ~2.1 GHz: the line carries the evidence.
+    Source: the amdgpu hwmon files of the device (`power1_average` / `power1_input` in microwatts, `freq1_input` in Hz) read in
+    place - no subprocess in the timed region (the rocm-smi fork every 1.5 s sat on the process that enqueues the launches).
+    Only where sysfs does not expose them does it fall back to forking `rocm-smi`; `how` in the result says which one ran.  Any
+    failure just leaves the fields out; `--no-power` switches it off and the line says so (`power: null`, `power_sampling: "off"`)."""
 
     def __init__(self, card: int):
         import threading
         self.card, self.samples, self._stop = card, [], threading.Event()
+        self._hw = self._find_hwmon(card)
+        self.how = "off"
         self._t = threading.Thread(target=self._run, daemon=True)
 
-    def _run(self):
+    @staticmethod
+    def _find_hwmon(card: int):
+        import glob
+        try:
+            pr = torch.cuda.get_device_properties(card)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            cands = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:                                          # noqa: BLE001
+            cands = []
+        if not cands and torch.cuda.device_count() == 1:
+            cands = [h for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")]
+        for h in cands:
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            fq = os.path.join(h, "freq1_input")
+            if pw and os.path.exists(fq):
+                return pw, fq
+        return None
+
+    def _read_sysfs(self):
+        pw, fq = self._hw
+        return float(open(pw).read()) / 1e6, float(open(fq).read()) / 1e6          # W, MHz
+
+    def _read_smi(self):
         import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(self.card), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        pw = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
+        sclk = next((float(str(v).strip("()").lower().replace("mhz", "")) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+        return pw, sclk
+
+    def _run(self):
+        read, period = (self._read_sysfs, 0.5) if self._hw else (self._read_smi, 1.5)
+        self.how = ("amdgpu hwmon sysfs (power1_average / freq1_input) read every ~0.5 s by a helper thread: no subprocess"
+                    if self._hw else "rocm-smi --showpower --showclocks forked every ~1.5 s (sysfs hwmon files not found)")
         while not self._stop.is_set():
             try:
-                out = subprocess.run(["rocm-smi", "-d", str(self.card), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-                card = next(iter(json.loads(out).values()))
-                pw = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
-                sclk = next((float(str(v).strip("()").lower().replace("mhz", "")) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+                pw, sclk = read()
                 if pw is not None and sclk is not None and sclk > 200:
                     self.samples.append((pw, sclk))
             except Exception:                                      # noqa: BLE001
+                if read == self._read_sysfs:                       # sysfs unreadable after all: one fall-back, then give up
+                    read, period, self.how = self._read_smi, 1.5, "rocm-smi --showpower --showclocks forked every ~1.5 s (sysfs read failed)"
+                    continue
                 return
-            self._stop.wait(1.5)
+            self._stop.wait(period)
 
     def start(self):
         self._t.start()
@@ -252,7 +289,7 @@ class PowerSampler:
             return None
         pw, ck = sorted(p for p, _ in self.samples), sorted(c for _, c in self.samples)
         return {"socket_power_w_p50": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "sclk_mhz_p50": ck[len(ck) // 2], "sclk_mhz_min": ck[0],
-                "samples": len(pw), "how": "rocm-smi --showpower --showclocks sampled every ~1.5 s during the timed steps"}
+                "samples": len(pw), "how": self.how + ", during the timed steps"}
 
 
 def self_launch(n: int) -> int:
@@ -368,10 +405,17 @@ def main():
     if args.fused_reduce >= 0:
         eng.set_option("decode_fused_reduce", args.fused_reduce)
 
-    # synthetic inputs, resident in HBM before the timed region
-    clip0 = rank * B
-    pixels = torch.cat([S.frames(F, clip0 + b, v["image_size"], device=dev) for b in range(B)], 0)     # [B*F, 3, H, W]
-    ids = [S.prompt_ids(F, clip0 + b, 30, l["vocab_size"]) for b in range(B)]
+    # synthetic inputs, resident in HBM before the timed region.  Clip i of the job's world * B clips belongs to rank i % world - the
+    # reference harness's round-robin `islice(docs, rank, None, world_size)` (lmms_eval/utils.py:675-681, aurora_amd.parallel.shard_clips).
+    # AURORA_BENCH_SHARD="k/n" is a TEST hook: a single process takes the clips of rank k of an n-rank job (tests compare them with the
+    # n-rank run's merged result clip by clip).
+    shard_rank, shard_world = rank, world
+    if os.environ.get("AURORA_BENCH_SHARD") and world == 1:
+        shard_rank, shard_world = (int(x) for x in os.environ["AURORA_BENCH_SHARD"].split("/"))
+    clip_ids = parallel.shard_clips(shard_world * B, shard_rank, shard_world)
+    assert len(clip_ids) == B
+    pixels = torch.cat([S.frames(F, c, v["image_size"], device=dev) for c in clip_ids], 0)     # [B*F, 3, H, W]
+    ids = [S.prompt_ids(F, c, 30, l["vocab_size"]) for c in clip_ids]
     Mseq = _rup(L0, 32)
     emb_all = torch.zeros(G * Mseq, l["hidden_size"], dtype=torch.float16, device=dev)
     plans = [eng.splice_plan(ids[b], F, n_kept) for b in range(B)]   # static per prompt: uploaded once, outside the loop
@@ -624,8 +668,10 @@ def main():
                                 evm0 = torch.cuda.Event(enable_timing=True)
                                 evm0.record(sDm)
                             eng.set_option("decode_half_grid", half_grid)   # half as many workgroups, twice the tiles each
-                            eng.decode(k1)
-                            eng.set_option("decode_half_grid", 0)
+                            try:
+                                eng.decode(k1)
+                            finally:                                        # a failed decode must not leave the ctx on the half grid
+                                eng.set_option("decode_half_grid", 0)
                             evm = torch.cuda.Event(enable_timing=k_cal["on"])
                             evm.record(sDm)
                             if k_cal["on"]:
@@ -750,6 +796,12 @@ def main():
     assert all(len(o) == N for o in out), [len(o) for o in out]        # EOS disabled: every clip produced N tokens
     import zlib
     ids_checksum = zlib.crc32(np.asarray(out, dtype=np.int32).tobytes())     # of this rank's last step: the same command must reproduce it
+    # the job's result in CLIP order: every rank's ids gathered (the path's one collective) and the round-robin shard undone
+    # (parallel.merge_round_robin; evaluator.py:519-546 gathers and re-orders the same way); one crc per clip goes into the line
+    per_rank_out = parallel.gather_results(out, N, B, cdev) if use_dist else {0: out}
+    job = parallel.merge_round_robin(per_rank_out, world * B) if use_dist else out
+    assert all(c is not None and len(c) == N for c in job), "a clip of the job has no result after the gather"
+    crc_per_clip = [zlib.crc32(np.asarray(c, dtype=np.int32).tobytes()) for c in job]
     per_rank_ms, gather_us = None, None
     if use_dist:
         # every rank's own clock around the same K steps (the line's time is their MAX), so that a slow rank or a slow link shows in
@@ -776,6 +828,7 @@ def main():
             "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "rccl_ranks": world if (use_dist and backend == "nccl") else (0 if use_dist else 1), "dist_backend": backend if use_dist else "none",
             "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_per_rank": per_rank_ms, "ids_all_gather_us": gather_us, "ids_checksum_rank0": ids_checksum,
+            "clips_of_rank0": clip_ids[:4] + (["..."] if len(clip_ids) > 4 else []), "ids_crc_per_clip": crc_per_clip,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("AuroraCap-7B-VID %d-frame video, token_kept_ratio=%g, greedy %d tokens (BASELINE configs[%d]%s)"
@@ -796,7 +849,7 @@ def main():
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "overlap_steps_calibration": (k_cal["info"] if (continuous and overlap) else None),
             "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
-            "power": power,
+            "power": power, "power_sampling": ("off" if not (rank == 0 and want_power) else (power or {}).get("how", "no samples")),
             "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
             "ttft_host_note": ("host clock from the moment a group's front end STARTS on the device (a helper thread waits for its first event) to its "
                                "first token ids sitting in pinned host memory (a side stream copies them after the commit; a second helper thread "

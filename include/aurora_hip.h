@@ -29,8 +29,11 @@ extern "C" {
 #define AUR_ERR_HIP -3      /* HIP runtime error */
 #define AUR_ERR_UNSUPPORTED -4 /* e.g. num_beams > 1 (cf. NotImplementedError at aurora.py:269-270) */
 
-#define AUR_ACT_QUICK_GELU 1
-#define AUR_ACT_GELU 2
+#define AUR_ACT_QUICK_GELU 1    /* x * sigmoid(1.702 x) */
+#define AUR_ACT_GELU 2          /* exact erf GELU (ACT2FN["gelu"]) */
+#define AUR_ACT_SILU 4          /* x * sigmoid(x) (ACT2FN["silu"] / ["swish"]) */
+#define AUR_ACT_RELU 5
+#define AUR_ACT_GELU_TANH 6     /* 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (ACT2FN["gelu_new"] / ["gelu_pytorch_tanh"]) */
 
 typedef struct aur_ctx aur_ctx;
 
@@ -41,7 +44,8 @@ typedef struct aur_config {
     int32_t vit_hidden, vit_heads, vit_layers, vit_mlp, vit_patch, vit_image, vit_channels;
     int32_t vit_act;            /* AUR_ACT_* from config.hidden_act */
     float vit_ln_eps;           /* config.layer_norm_eps (pre_layrnorm); encoder layers use 1e-5 (aurora.py:709) */
-    /* projector (modeling_projector.py:20-33): vit_hidden -> llm_hidden -> llm_hidden, erf-GELU */
+    /* projector (modeling_projector.py:20-33, configuration_projector.py:9-22): Linear(vit_hidden, llm_hidden), then (act, Linear(llm_hidden,
+     * llm_hidden)) x (depth - 1); depth / hidden_act come from projector/config.json through proj_depth / proj_act at the end of this struct */
     /* language model: HF LlamaConfig */
     int32_t llm_hidden, llm_heads, llm_layers, llm_mlp, llm_vocab;
     float llm_rms_eps, rope_theta, rope_factor;   /* linear RoPE scaling factor (vicuna-16k: 4.0) */
@@ -57,6 +61,8 @@ typedef struct aur_config {
                                  * 0 = vit_image.  vit_image is then the CAPACITY: the largest input side aur_vit_encode_hw accepts */
     int32_t spare_slots;        /* extra KV sequences per bank beyond max_batch (ids max_batch .. max_batch + spare_slots - 1): targets of
                                  * aur_llm_prefill_stage while every decode slot is still generating.  0 = none */
+    int32_t proj_depth;         /* ProjectorConfig.depth: number of Linear layers, 1 .. 8; 0 = 2 (the AuroraCap checkpoints) */
+    int32_t proj_act;           /* AUR_ACT_* of ProjectorConfig.hidden_act between the Linear layers; 0 = AUR_ACT_GELU */
 } aur_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -67,7 +73,7 @@ const char* aur_version(void);
 
 /* Named device tensors (weights in kernel layout).  Replaces the three from_pretrained loads at
  * inference.py:46-57.  Names and layouts: aurora_amd/engine.py::_load_vit / _load_llm / _load_projector
- * (e.g. "vit.3.qkv.w", "llm.7.down.w", "proj.fc1.b"). */
+ * (e.g. "vit.3.qkv.w", "llm.7.down.w", "proj.0.w" / "proj.0.b" .. "proj.<depth-1>.b"; a bias-free projector passes zeros). */
 int aur_set_tensor(aur_ctx* ctx, const char* name, const void* dev_ptr, int64_t nbytes);
 /* Caller-owned scratch; sizes from the two queries (depend only on cfg). */
 int64_t aur_workspace_bytes(const aur_ctx* ctx);

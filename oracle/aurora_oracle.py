@@ -237,10 +237,20 @@ def vit_features(pixels, vw, cfg, token_kept_ratio, q: Q = None, capture=None):
 # --------------------------------------------------------------------------
 # projector + splice  (modeling_projector.py:20-51, model/utils.py:138-295)
 # --------------------------------------------------------------------------
-def projector(x, pw, q: Q = None):
+_ACT = {"gelu": F.gelu, "quick_gelu": lambda x: x * torch.sigmoid(1.702 * x), "silu": F.silu, "swish": F.silu, "relu": F.relu,
+        "gelu_new": lambda x: F.gelu(x, approximate="tanh"), "gelu_pytorch_tanh": lambda x: F.gelu(x, approximate="tanh")}
+
+
+def projector(x, pw, q: Q = None, hidden_act: str = "gelu"):
+    """modeling_projector.py:20-33: `model.0`, then (`ACT2FN[hidden_act]`, Linear `model.2k`) x (depth - 1), depth read off the keys;
+    `bias=False` checkpoints simply have no bias keys (configuration_projector.py:9-22)"""
     q = q or _id
-    h = q(F.gelu(F.linear(x, pw["model.0.weight"], pw["model.0.bias"])))
-    return q(F.linear(h, pw["model.2.weight"], pw["model.2.bias"]))
+    depth = sum(1 for k in pw if k.endswith(".weight"))
+    h = x
+    for i in range(depth):
+        h = F.linear(h, pw[f"model.{2 * i}.weight"], pw.get(f"model.{2 * i}.bias"))
+        h = q(_ACT[hidden_act](h)) if i < depth - 1 else q(h)
+    return h
 
 
 def splice(input_ids: torch.Tensor, embed_table: torch.Tensor, visual: torch.Tensor) -> torch.Tensor:
@@ -274,12 +284,12 @@ def splice_slowfast(input_ids: torch.Tensor, embed_table: torch.Tensor, visual: 
     return torch.cat(out, dim=0)
 
 
-def visual_features_slowfast(pixels, vw, pw, cfg, token_kept_ratio, q: Q = None) -> List[torch.Tensor]:
+def visual_features_slowfast(pixels, vw, pw, cfg, token_kept_ratio, q: Q = None, hidden_act: str = "gelu") -> List[torch.Tensor]:
     """aurora.py:223-246: frames 1.. at the current ratio, then frame 0 at ratio 1.0 (unmerged); each projected.
     Returns the list [frame0 [n0, d], frame1 [n, d], ...] that the slow-fast splice consumes."""
     low = vit_features(pixels[1:], vw, cfg, token_kept_ratio, q)
     high = vit_features(pixels[:1], vw, cfg, 1.0, q)
-    return [projector(high[0], pw, q)] + [projector(x, pw, q) for x in low]
+    return [projector(high[0], pw, q, hidden_act)] + [projector(x, pw, q, hidden_act) for x in low]
 
 
 def build_prompt(prompt: str, num_images: int) -> str:
@@ -386,7 +396,7 @@ def caption_ids(pixels, input_ids, weights, cfg, token_kept_ratio, max_new_token
     t0 = time.perf_counter()
     feats = vit_features(pixels, weights["vit"], cfg["vit"], token_kept_ratio, q)    # [f, n, Dv]
     f, n, dv = feats.shape
-    vis = projector(feats.reshape(1, f * n, dv), weights["projector"], q).reshape(f, n, -1)
+    vis = projector(feats.reshape(1, f * n, dv), weights["projector"], q, (cfg.get("projector") or {}).get("hidden_act", "gelu")).reshape(f, n, -1)
     emb = splice(torch.tensor(input_ids), weights["llm"]["embed_tokens.weight"], vis)
     t1 = time.perf_counter()
     ids, logits = llama_greedy(emb, weights["llm"], cfg["llm"], max_new_tokens, eos_id, q, return_logits=True)

@@ -109,3 +109,58 @@ def test_cli_path_pieces_against_the_reference_side_run():
                         eos_id=cfg["llm"]["eos_token_id"], q=None)
     assert out == g["ids"].tolist()
     assert tok.batch_decode([out], skip_special_tokens=True)[0] == str(g["text"])
+
+
+# ---- G15: projector/config.json is read and honoured.  Directories written by the reference's own
+# ProjectorModel.save_pretrained for every shape ProjectorModel.__init__ can build (modeling_projector.py:20-33,
+# configuration_projector.py:9-22); outputs computed by the reference module (tests/golden/make_golden_projector.py).
+PV = os.path.join(HERE, "golden", "proj_variants")
+G15 = os.path.join(HERE, "golden", "g15_projector_variants.npz")
+PV_OK = {"d3_silu": (3, "silu", True), "d1": (1, "gelu", True), "d2_nobias": (2, "gelu", False), "d2_tanh": (2, "gelu_pytorch_tanh", True),
+         "d2_relu": (2, "relu", True), "d2_quick": (2, "quick_gelu", True)}
+
+
+@pytest.mark.parametrize("name", sorted(PV_OK))
+def test_projector_config_is_read_and_the_oracle_reproduces_the_reference_module(name):
+    from aurora_amd.engine import projector_settings
+    g = np.load(G15)
+    pc = CK.projector_config(os.path.join(PV, name))
+    assert (pc["depth"], pc["hidden_act"], pc["bias"]) == PV_OK[name] and pc["visual_hidden_size"] == 64 and pc["llm_hidden_size"] == 128
+    assert projector_settings(pc, 64, 128) == dict(depth=pc["depth"], hidden_act=pc["hidden_act"], bias=pc["bias"])
+    pw = CK.projector_weights(CK._load_state(os.path.join(PV, name)), pc)
+    assert len([k for k in pw if k.endswith(".weight")]) == pc["depth"] and any(k.endswith(".bias") for k in pw) == pc["bias"]
+    y = O.projector(torch.from_numpy(g["x"]), {k: v.float() for k, v in pw.items()}, None, pc["hidden_act"])
+    ref = torch.from_numpy(g["y_" + name])
+    assert (y - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_projector_config_the_kernels_cannot_honour_raises_instead_of_loading_wrong():
+    from aurora_amd.engine import projector_settings
+    pc = CK.projector_config(os.path.join(PV, "d2_mish"))
+    assert pc["hidden_act"] == "mish"
+    with pytest.raises(NotImplementedError, match="mish"):
+        projector_settings(pc, 64, 128)
+    with pytest.raises(NotImplementedError, match="depth"):
+        projector_settings(dict(depth=9), 64, 128)
+    with pytest.raises(ValueError, match="visual_hidden_size"):
+        projector_settings(CK.projector_config(os.path.join(PV, "d1")), 1280, 128)
+    # weights that do not match the config (a depth-3 config over a depth-2 file, a bias-free config over biased weights)
+    sd2 = CK._load_state(os.path.join(PV, "d2_relu"))
+    with pytest.raises(KeyError, match="model.4"):
+        CK.projector_weights(sd2, dict(depth=3, bias=True))
+    with pytest.raises(KeyError, match="unexpected"):
+        CK.projector_weights(sd2, dict(depth=2, bias=False))
+
+
+def test_whole_directory_with_a_mismatched_projector_config_is_rejected(tmp_path):
+    """load_auroracap cross-checks projector/config.json against the tower and the language model it sits between"""
+    import shutil
+    root = tmp_path / "ckpt"
+    shutil.copytree(ROOT, root)
+    cfg, w = CK.load_auroracap(str(root))
+    assert cfg["projector"] == dict(visual_hidden_size=64, llm_hidden_size=128, depth=2, hidden_act="gelu", bias=True)
+    pj = json.load(open(root / "projector" / "config.json"))
+    pj["visual_hidden_size"] = 1280
+    json.dump(pj, open(root / "projector" / "config.json", "w"))
+    with pytest.raises(ValueError, match="visual_hidden_size"):
+        CK.load_auroracap(str(root))

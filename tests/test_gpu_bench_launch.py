@@ -154,3 +154,30 @@ def test_config_presets_and_self_diagnosing_fields():
     assert d["ids_all_gather_us"] > 0
     assert d["p50_ttft_host_ms"] is not None and d["p50_ttft_host_ms"] > 0
     assert d["ttft_host_ms_single_clip"] >= d["ttft_ms_single_clip"] * 0.9
+
+
+def test_eight_rank_dry_run_of_the_configs3_command():
+    """`python bench.py --gpus 8 --config cfg4` IS BASELINE configs[3] (64 clips sharded 8-way).  No 8-GPU node has been available, so the
+    literal command runs here with tiny model dims and gloo: bench.py launches its own 8 ranks (8 processes sharing this box's GPU),
+    they rendezvous on 127.0.0.1, shard the 64 clips round-robin (clip i -> rank i % 8, lmms_eval/utils.py:675-681), time their steps
+    on their own clocks, all_gather the ids every cycle and rank 0 merges them back into clip order (evaluator.py:519-546).
+    The merged order is checked against an independent run: a single process that takes rank 3's shard (AURORA_BENCH_SHARD=3/8) must
+    produce exactly the ids the 8-rank job reports for clips 3, 11, 19, ..."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["AURORA_DIST_BACKEND"] = "gloo"
+    common = ["--config", "cfg4", "--tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-power"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + common, cwd=ROOT, capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["dist_backend"] == "gloo" and d["config"]["preset"] == "cfg4" and d["config"]["clips_per_gpu_per_step"] == 8
+    assert d["config"]["frames"] == 8 and d["config"]["max_new_tokens"] == 256 and d["config"]["token_kept_ratio"] == 0.3
+    assert len(d["ms_per_step_per_rank"]) == 8 and max(d["ms_per_step_per_rank"]) == pytest.approx(d["ms_per_step"])
+    assert d["value"] == pytest.approx(64 / (d["ms_per_step"] / 1e3), rel=1e-6)              # whole-job aggregate: 64 clips per step
+    assert len(d["ids_crc_per_clip"]) == 64 and d["clips_of_rank0"][:4] == [0, 8, 16, 24]
+    env1 = dict(env, AURORA_BENCH_SHARD="3/8")
+    env1.pop("AURORA_DIST_BACKEND")
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env1)
+    assert r1.returncode == 0, (r1.stdout[-2000:], r1.stderr[-3000:])
+    d1 = _json_line(r1.stdout)
+    assert d1["clips_of_rank0"][:4] == [3, 11, 19, 27]
+    assert d1["ids_crc_per_clip"] == d["ids_crc_per_clip"][3::8]

@@ -124,3 +124,32 @@ def test_g8_projector_through_the_gemm_kernels():
         assert rel_l2(out, want) < 5e-3 and (out - want).abs().max().item() <= 2e-2 * want.abs().max().item()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["d3_silu", "d1", "d2_nobias", "d2_tanh", "d2_relu", "d2_quick"])
+def test_g15_projector_variants_through_the_engine(name):
+    """projector/config.json honoured by the kernels: directories written by the reference's ProjectorModel.save_pretrained
+    (depth 1 / 2 / 3, silu / relu / tanh-GELU / quick-GELU epilogues, bias False) -> checkpoint.projector_config -> engine ->
+    aur_project_splice, against the reference module's own outputs (g15_projector_variants.npz)."""
+    import os
+    from aurora_amd import checkpoint as CK
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.util import rand_llm_weights
+    g = golden("g15_projector_variants.npz")
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proj_variants", name)
+    pc = CK.projector_config(d)
+    pw = CK.projector_weights(CK._load_state(d), pc)
+    vcfg = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, patch_size=14, image_size=28, hidden_act="quick_gelu")
+    lcfg = dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=128, vocab_size=128, rms_norm_eps=1e-5, rope_theta=1e4)
+    eng = AuroraCapEngine({"vit": vcfg, "llm": lcfg, "projector": pc}, {"llm": rand_llm_weights(lcfg, 5), "projector": pw}, max_frames=1, max_batch=1,
+                          max_ctx=128, max_new_tokens=8)
+    try:
+        x = tt(g["x"])                                                     # [24, 64] visual tokens
+        ids = [1, 7] + [-200] + [9]                                        # one image marker: its 24 rows land at positions 2 .. 25
+        emb, L = eng.project_splice(x.half().cuda()[None], ids)
+        assert L == 3 + 24
+        out = emb[2:26].float().cpu()
+        want = tt(g["y_" + name])
+        assert rel_l2(out, want) < 5e-3 and (out - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    finally:
+        eng.close()

@@ -57,7 +57,8 @@ def test_checkpoint_directory_round_trip(tmp_path):
                    vocab_size=320, rms_norm_eps=1e-5, rope_theta=1e4, rope_scaling={"type": "linear", "factor": 4.0},
                    eos_token_id=2), open(root / "config.json", "w"))
     save_file({k: v.contiguous() for k, v in pw.items()}, str(root / "projector" / "model.safetensors"))
-    json.dump({}, open(root / "projector" / "config.json", "w"))
+    json.dump({"visual_hidden_size": pw["model.0.weight"].shape[1], "llm_hidden_size": 128, "depth": 2, "hidden_act": "gelu", "bias": True},
+              open(root / "projector" / "config.json", "w"))            # what ProjectorConfig.save_pretrained writes (configuration_projector.py:9-22)
     cfg, w = checkpoint.load_auroracap(str(root))
     assert cfg["vit"]["hidden_act"] == "gelu" and cfg["vit"]["layer_norm_eps"] == 1e-6        # read from config, not hard-coded
     assert cfg["llm"]["rope_factor"] == 4.0 and cfg["llm"]["eos_token_id"] == 2
