@@ -40,7 +40,14 @@ template <int TAG> struct G2Lab {
     static constexpr bool no_dma = id == 5;
     static constexpr bool no_mfma = id == 6;
     static constexpr bool a_tiled = id == 7;
+    static constexpr bool ts = id == 8;          // s_memtime stamps around every segment of every phase -> g2_ts (aur_lab_gemm_ts)
 };
+#ifdef AUR_LABS
+// lab 8: per workgroup and wave, cycles summed over the K loops of all its tiles, [phase 0..3][load segment, barrier 1, lgkmcnt wait,
+// MFMA burst, barrier 2], then [20] = phases timed, [21] = total cycles of the K loops.  Stamps are s_memtime (SMEM: counted by lgkmcnt)
+// issued WITHOUT a wait of their own: they are collected behind the schedule's existing s_waitcnt lgkmcnt(0).
+__device__ unsigned g2_ts[256 * 8 * 24];
+#endif
 template <int AUX>
 __device__ __forceinline__ void glds16x(const void* gsrc_lane, void* lds_wave_base) {
     if constexpr (AUX == 0) __builtin_amdgcn_global_load_lds(GPTR(gsrc_lane), LPTR(lds_wave_base), 16, 0, 0);
@@ -152,9 +159,36 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
             wf[tt * 2 + 1] = *(const h8*)(buf + w_off + (nh * 2 + tt) * 2048 + 1024);
         }
     };
+    // ---- lab 8 (AUR_LABS): segment stamps.  tA: phase start, tB: before barrier 1, tC: after it, tD: after the lgkmcnt wait, tE: after
+    // the MFMA burst.  Everything compiles away when G2Lab<TAG>::ts is false.
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tCp = 0, tDp = 0, tEp = 0, tK0 = 0;
+    unsigned tacc[4][5] = {{0}}, tphases = 0;
+    bool thave = false;
+#define G2_TS(v)                                                      \
+    do {                                                              \
+        if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0" : "=s"(v)); \
+    } while (0)
+#define G2_TS_COLLECT(P)                                                                                     \
+    do {                                                                                                     \
+        if constexpr (G2Lab<TAG>::ts) {                                                                      \
+            asm volatile("" : "+s"(tA), "+s"(tB), "+s"(tC), "+s"(tDp), "+s"(tEp));   /* behind the lgkmcnt(0) above */ \
+            tacc[P][0] += (unsigned)(tB - tA);                                                               \
+            tacc[P][1] += (unsigned)(tC - tB);                                                               \
+            if (thave) {                                                                                     \
+                tacc[((P) + 3) & 3][2] += (unsigned)(tDp - tCp);                                             \
+                tacc[((P) + 3) & 3][3] += (unsigned)(tEp - tDp);                                             \
+                tacc[((P) + 3) & 3][4] += (unsigned)(tA - tEp);                                              \
+                ++tphases;                                                                                   \
+            }                                                                                                \
+            thave = true;                                                                                    \
+            tCp = tC;                                                                                        \
+        }                                                                                                    \
+    } while (0)
 #define G2_COMPUTE(NH, MH, wf)                                                                                   \
     do {                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        G2_TS_COLLECT(((NH) == 0 && (MH) == 0) ? 0 : ((NH) == 1 && (MH) == 0) ? 1 : ((NH) == 1 && (MH) == 1) ? 2 : 3); \
+        G2_TS(tD);                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         if (G2Lab<TAG>::no_mfma) __builtin_amdgcn_s_sleep(4);      /* lab: the burst's duration without its power */ \
@@ -168,6 +202,9 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
                         acc[(NH) * 2 + tt][(MH) * 4 + uu] = mfma16(wf[tt * 2 + kk], af[uu * 2 + kk], acc[(NH) * 2 + tt][(MH) * 4 + uu]); \
                 }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                       \
+        G2_TS(tE);                                                                                           \
+        tDp = tD;                                                                                            \
+        tEp = tE;                                                                                            \
     } while (0)
 
     // ---- the prologue was issued by the caller: K-tile 0 must have landed, W0, W1, A0 of K-tile 1 may stay in flight
@@ -176,6 +213,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
     G2_BARRIER();
     if (wr == 1) G2_BARRIER();                    // stagger: waves 4-7 run one barrier behind
 
+    if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK0));
     int wb = 0;                                            // weight buffer of K-tile t (t % 3)
     for (int t = 0; t < nkt; ++t) {
         const char* abuf = smem + (t & 1) * G2_ABUF;
@@ -183,37 +221,64 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
         const int wb2 = wb == 0 ? 2 : wb - 1;              // (t + 2) % 3
         const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;     // block-uniform
         // phase 0: quadrant (n half 0, m half 0)
+        G2_TS(tA);
         read_a(abuf, 0);
         read_w(wbuf, 0, wf0);
         if (n1) stage_a(1, t + 1);
+        G2_TS(tB);
         G2_BARRIER();
+        G2_TS(tC);
         G2_COMPUTE(0, 0, wf0);
         G2_BARRIER();
         // phase 1: (n half 1, m half 0)
+        G2_TS(tA);
         read_w(wbuf, 1, wf1);
         if (n2) stage_w(0, t + 2, wb2);
+        G2_TS(tB);
         G2_BARRIER();
+        G2_TS(tC);
         G2_COMPUTE(1, 0, wf1);
         G2_BARRIER();
         // phase 2: (n half 1, m half 1)
+        G2_TS(tA);
         read_a(abuf, 1);
         if (n2) stage_w(1, t + 2, wb2);
+        G2_TS(tB);
         G2_BARRIER();
+        G2_TS(tC);
         G2_COMPUTE(1, 1, wf1);
         G2_BARRIER();
         // phase 3: (n half 0, m half 1); retire K-tile t+1's half-tiles, keep W0, W1, A0 of t+2 in flight
+        G2_TS(tA);
         if (n2) {
             stage_a(0, t + 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        G2_TS(tB);
         G2_BARRIER();
+        G2_TS(tC);
         G2_COMPUTE(0, 1, wf0);
         G2_BARRIER();
         wb = wb == 2 ? 0 : wb + 1;
     }
     if (wr == 0) G2_BARRIER();                    // match the stagger barrier of waves 4-7
+#ifdef AUR_LABS
+    if constexpr (G2Lab<TAG>::ts) {
+        unsigned long long tK1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK1));
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned* o = g2_ts + (blockIdx.x * 8 + w) * 24;
+            for (int p = 0; p < 4; ++p)
+                for (int q = 0; q < 5; ++q) o[p * 5 + q] += tacc[p][q];
+            o[20] += tphases;
+            o[21] += (unsigned)(tK1 - tK0);
+        }
+    }
+#endif
+#undef G2_TS
+#undef G2_TS_COLLECT
 #undef G2_COMPUTE
 }
 
@@ -385,7 +450,7 @@ hipError_t gemm256_init() {
     if ((e = g2_attr<EPI_ROW, GT_LAB_BASE + 1>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 2>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 3>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 4>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 5>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 6>()) != hipSuccess ||
-        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess)
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 8>()) != hipSuccess)
         return e;
 #endif
     return hipSuccess;
@@ -418,6 +483,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 5: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 5); break;
             case 6: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 6); break;
             case 7: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 7); break;
+            case 8: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 8); break;
             default: return hipErrorInvalidValue;
         }
 #endif
@@ -441,3 +507,15 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
 #undef G2_LAUNCH
     return hipGetLastError();
 }
+
+#ifdef AUR_LABS
+// lab 8 read-out (libaurora_hip_labs.so only; not part of include/aurora_hip.h): copies g2_ts to the host and clears it
+extern "C" int aur_lab_gemm_ts(unsigned* dst_host, int clear) {
+    if (hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g2_ts), sizeof(unsigned) * 256 * 8 * 24) != hipSuccess) return -1;
+    if (clear) {
+        static unsigned zeros[256 * 8 * 24];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g2_ts), zeros, sizeof zeros) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
