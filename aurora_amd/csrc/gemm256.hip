@@ -295,77 +295,91 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
 // half of activation buffer 1): the prologue's DMA is already in flight while this runs.
 #define G2_SLAB_STRIDE 272
 #define G2_SLAB_BYTES (16 * G2_SLAB_STRIDE)
-__device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem) {
+// One 16-row block (u) of the wave's 128 x 64 region.  U is a TEMPLATE parameter on purpose: rounds 2-3 wrote this as `#pragma unroll
+// for (int u ..)`, the body outgrew LLVM's pragma-unroll threshold, the loop stayed rolled, `acc[t][u]` became a runtime index and
+// hipcc moved the whole accumulator array to SCRATCH (528 B per lane: 32 zero stores + 32 stores + 32 loads of 1 KiB per wave and
+// tile, 512 KiB of scratch traffic per 128 KiB output tile; round 4 found it in the .s: `.private_segment_fixed_size 528`).  With a
+// compile-time U every accumulator index is static and the array stays in registers (tests/test_static_asm.py pins 0 bytes of scratch).
+template <int U>
+__device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], int mb, int nb, int lane, char* slab) {
     const int r = lane & 15, g = lane >> 4;
+    const int row0 = lane >> 3, chunk = lane & 7;
+    const int n = nb + chunk * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[t][U][i] + bias[t][i];
+        if (a.act == ACT_QUICK_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
+        } else if (a.act == ACT_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+        } else if (a.act >= ACT_SILU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+        }
+        *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
+    }
+    asm volatile("" ::: "memory");                       // LDS writes above, reads below: same wave, program order
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = hh * 8 + row0;
+        const int m = mb + U * 16 + row;
+        const f4 x0 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32);
+        const f4 x1 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16);
+        if (m >= a.M || n >= a.n_real) continue;
+        const int orow = a.out_rows ? a.out_rows[m] : m;
+        if (orow < 0) continue;
+        if (a.act == ACT_SILU_MUL) {                     // (gate, up) interleaved: 4 outputs at columns n / 2 .. n / 2 + 3
+            h4 o;
+            o[0] = (half_t)(silu_f(x0[0]) * x0[1]);
+            o[1] = (half_t)(silu_f(x0[2]) * x0[3]);
+            o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
+            o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
+            half_t* dst = a.C + (int64_t)orow * a.ldc + (n >> 1);
+            if (n + 8 <= a.n_real) *(h4*)dst = o;
+            else *(h2*)dst = h2{o[0], o[1]};             // n_real % 4 == 0: the chunk holds 4 real columns
+        } else {
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            const bool full = n + 8 <= a.n_real;
+            if (a.resid) {
+                const half_t* rp = a.resid + (int64_t)m * a.ldr + n;
+                if (full) {
+                    const h8 rr = *(const h8*)rp;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
+                } else {
+                    const h4 rr = *(const h4*)rp;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+                }
+            }
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
+            half_t* dst = a.C + (int64_t)orow * a.ldc + n;
+            if (full) *(h8*)dst = o;
+            else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem) {
+    const int g = lane >> 4;
     char* slab = w < 6 ? smem + G2_WBASE + 2 * G2_WBUF + w * G2_SLAB_BYTES : smem + G2_ABUF + G2_SLOT + (w - 6) * G2_SLAB_BYTES;
     f4 bias[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bias[t] = a.bias ? *(const f4*)(a.bias + nb + t * 16 + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
-    const int row0 = lane >> 3, chunk = lane & 7;
-    const int n = nb + chunk * 8;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[t][u][i] + bias[t][i];
-            if (a.act == ACT_QUICK_GELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
-            } else if (a.act == ACT_GELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
-            } else if (a.act >= ACT_SILU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
-            }
-            *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
-        }
-        asm volatile("" ::: "memory");                       // LDS writes above, reads below: same wave, program order
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int row = hh * 8 + row0;
-            const int m = mb + u * 16 + row;
-            const f4 x0 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32);
-            const f4 x1 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16);
-            if (m >= a.M || n >= a.n_real) continue;
-            const int orow = a.out_rows ? a.out_rows[m] : m;
-            if (orow < 0) continue;
-            if (a.act == ACT_SILU_MUL) {                     // (gate, up) interleaved: 4 outputs at columns n / 2 .. n / 2 + 3
-                h4 o;
-                o[0] = (half_t)(silu_f(x0[0]) * x0[1]);
-                o[1] = (half_t)(silu_f(x0[2]) * x0[3]);
-                o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
-                o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
-                half_t* dst = a.C + (int64_t)orow * a.ldc + (n >> 1);
-                if (n + 8 <= a.n_real) *(h4*)dst = o;
-                else *(h2*)dst = h2{o[0], o[1]};             // n_real % 4 == 0: the chunk holds 4 real columns
-            } else {
-                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                const bool full = n + 8 <= a.n_real;
-                if (a.resid) {
-                    const half_t* rp = a.resid + (int64_t)m * a.ldr + n;
-                    if (full) {
-                        const h8 rr = *(const h8*)rp;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
-                    } else {
-                        const h4 rr = *(const h4*)rp;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
-                    }
-                }
-                h8 o;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
-                half_t* dst = a.C + (int64_t)orow * a.ldc + n;
-                if (full) *(h8*)dst = o;
-                else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
+    g2_epilogue_row_u<0>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<1>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<2>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<3>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<4>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<5>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<6>(a, acc, bias, mb, nb, lane, slab);
+    g2_epilogue_row_u<7>(a, acc, bias, mb, nb, lane, slab);
 }
 
 template <int EPI, int TAG>

@@ -78,3 +78,21 @@ def test_compiled_decode_kernels_have_no_unpadded_inline_asm_store(tmp_path):
     # the hand-over's partial stores are there, as compiler-emitted write-through buffer stores
     assert re.search(r"buffer_store_dwordx4 .* sc1", asm)
     assert not re.search(r"global_store_dwordx4 .* sc1", asm)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_the_front_end_gemm_keeps_its_accumulators_out_of_scratch(tmp_path):
+    """Rounds 2-3 shipped gemm256_kernel<EPI_ROW, *> with `.private_segment_fixed_size 528`: the wide epilogue's `#pragma unroll` loop
+    over the 8 row blocks outgrew LLVM's pragma-unroll threshold, stayed rolled, `acc[t][u]` became a runtime index and the 128
+    accumulators went to scratch - 512 KiB of scratch traffic per 128 KiB output tile.  The row block is a template parameter now
+    (gemm256.hip g2_epilogue_row_u); no kernel of the file may own scratch or spill."""
+    out = tmp_path / "gemm256.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "gemm256.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm)]
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s*(\d+)", asm)]
+    assert len(sizes) >= 10 and all(v == 0 for v in sizes), sizes
+    assert all(v == 0 for v in spills), spills
+    assert "scratch_" not in asm

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Where does a K-tile of the 256x256 GEMM go?  (lab tool; needs `python -m aurora_amd.build --labs`)
+
+Runs gemm256.hip's lab instantiation 8 - the product kernel with s_memtime stamps around every segment of every phase, collected behind the
+schedule's own lgkmcnt waits - on the path's shapes and prints, per phase, mean cycles per wave of
+    load (LDS fragment reads + LDS-DMA issue) | barrier 1 | lgkmcnt wait | MFMA burst (16 MFMAs) | barrier 2
+for the leading group (waves 0-3) and the trailing group (waves 4-7).  An ideal phase is 2 x 272 cycles (each group's burst hides the
+other's load segment).
+
+    AURORA_HIP_SO=aurora_amd/libaurora_hip_labs.so python tools/gemm_lab/ts_probe.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("AURORA_HIP_SO", os.path.join(ROOT, "aurora_amd", "libaurora_hip_labs.so"))
+
+
+def main():
+    from aurora_amd._lib import check
+    from aurora_amd.engine import AuroraCapEngine, _rup
+    eng = AuroraCapEngine({"vit": None, "llm": None}, {}, max_frames=1, max_batch=1)
+    L = eng.L
+    L.aur_lab_gemm_ts.restype = C.c_int
+    L.aur_lab_gemm_ts.argtypes = [C.c_void_p, C.c_int]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ts = np.zeros(256 * 8 * 24, dtype=np.uint32)
+
+    def run(name, M, K, N, lab, iters=8):
+        npad = _rup(N, 256)
+        a = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+        w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+        wp = eng.pack(w, npad, K)
+        bias = torch.zeros(npad, device="cuda")
+        c = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        eng.set_option("gemm_mode", 2)
+        eng.set_option("gemm_lab", lab)
+        st = eng._stream()
+        call = lambda: check(eng.ctx, L.aur_linear(eng.ctx, a.data_ptr(), M, K, wp.data_ptr(), npad, N, bias.data_ptr(), 0, None, c.data_ptr(), st), "aur_linear")
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        print(f"\n{name}: M {M} K {K} N {N} lab {lab}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
+        if lab != 8:
+            return
+        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
+        t = ts.reshape(256, 8, 24).astype(np.float64)
+        for grp, ws in (("waves 0-3 (leading group)", slice(0, 4)), ("waves 4-7 (one barrier behind)", slice(4, 8))):
+            x = t[:, ws].reshape(-1, 24)
+            x = x[x[:, 20] > 0]
+            n = x[:, 20].sum()
+            seg = x[:, :20].sum(0).reshape(4, 5) / (n / 4.0)        # mean cycles per phase occurrence
+            tot = x[:, 21].sum() / n
+            print(f"  {grp}: mean cycles per phase {tot:7.1f} (ideal 2 x 272 = 544)")
+            print("    phase   load   bar1   lgkm   mfma   bar2    sum")
+            for p in range(4):
+                print(f"    {p}     " + " ".join(f"{v:6.0f}" for v in seg[p]) + f" {seg[p].sum():6.0f}")
+        eng.set_option("gemm_lab", 0)
+
+    for lab in (0, 8):
+        run("llm gate/up, 4-clip prefill pass", 8576, 4096, 22016, lab)
+    for lab in (0, 8):
+        run("vit fc1, t = 640 x 32 frames", 20480, 1280, 5120, lab)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
