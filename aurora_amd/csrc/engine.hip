@@ -5,6 +5,8 @@
 //   aur_vit_encode      <- AuroraEncoder.forward + AuroraCLIPEncoder loop   (aurora.py:883-904, 772-860, 713-759)
 //   aur_project_splice  <- projector + prepare_inputs_labels_for_multimodal (aurora.py:254-258, utils.py:138-295)
 //   aur_llm_prefill / aur_llm_decode <- LlamaForCausalLM.generate greedy    (inference.py:89-96)
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -106,7 +108,7 @@ struct aur_ctx {
         size_t used = 0;
         double ms = 0;
         int64_t n = 0;
-    } kev[2];                                            // 0: decode attention (main kernel), 1: gate/up GEMV
+    } kev[4];                                            // 0: decode attention (main kernel), 1: gate/up GEMV, 2: ToMe step (3 launches), 3: lm_head + argmax
 };
 
 static std::string g_create_err;
@@ -467,7 +469,30 @@ extern "C" int aur_pack_linear(aur_ctx* ctx, const void* w, int32_t n_src, int32
 }
 
 // ------------------------------------------------------------------------------------------ profiling
+// roctx ranges per stage (tracing): `rocprofv3 --marker-trace --kernel-trace` then groups the launches of a stage under
+// its name instead of by kernel name only.  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so)
+// when AURORA_ROCTX=1 is set - the product library has no link-time dependency on a profiler, and without the variable a range costs one
+// predictable branch.  Ranges bracket the host-side ENQUEUE of a stage (what roctx measures); the device time is in the kernel trace.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* on = getenv("AURORA_ROCTX");
+        if (!on || on[0] != '1') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const Roctx& roctx() {
+    static Roctx r;          // read-only after its thread-safe initialisation
+    return r;
+}
 static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
+    if (roctx().push) roctx().push(name);
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
     if (!t.e0) {
@@ -484,6 +509,7 @@ static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
     (void)hipEventRecord(t.e0, s);
 }
 static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
+    if (roctx().pop) roctx().pop();
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
     (void)hipEventRecord(t.e1, s);
@@ -530,7 +556,7 @@ static void kev_end(aur_ctx::KernelEvents& k, hipStream_t s) {
     if (k.used >= 4096) kev_fold(k);
 }
 extern "C" int aur_profile_read(aur_ctx* ctx, const char* stage, double* ms_out, int64_t* launches_out) {
-    const int which = !strcmp(stage, "decode_attn") ? 0 : !strcmp(stage, "decode_gemm_gateup") ? 1 : -1;
+    const int which = !strcmp(stage, "decode_attn") ? 0 : !strcmp(stage, "decode_gemm_gateup") ? 1 : !strcmp(stage, "vit_tome") ? 2 : !strcmp(stage, "first_token") ? 3 : -1;
     if (which >= 0) {
         kev_fold(ctx->kev[which]);
         if (ms_out) *ms_out = ctx->kev[which].ms;
@@ -605,7 +631,9 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
         ta.x = x; ta.size = size; ta.t_out_pad = rup(t2, 32); ta.x_out = x_alt; ta.size_out = size_alt;
         ta.node_max = ctx->w_nmax; ta.node_idx = ctx->w_nidx; ta.unm = ctx->w_unm; ta.src = ctx->w_src; ta.dst = ctx->w_dst;
         ta.mhat = ctx->w_mhat;
+        if (ctx->prof) kev_begin(ctx->kev[2], s);
         CK(launch_tome_step(ta, s));                                                       // aurora.py:746-747
+        if (ctx->prof) kev_end(ctx->kev[2], s);
         xc = x_alt;
         sc = size_alt;
     }
@@ -997,9 +1025,11 @@ static int prefill_layers(aur_ctx* ctx, int seq0, int nseq, void* embeds, int se
 static int prefill_first_tokens(aur_ctx* ctx, int slot0, int nseq, void* embeds, int seq_len, hipStream_t s, const char* stage = "prefill") {
     const aur_config& g = ctx->cfg;
     const int d = g.llm_hidden, Mseq = rup(seq_len, 32);
+    if (ctx->prof) kev_begin(ctx->kev[3], s);
     CK(launch_xfrag_norm((half_t*)embeds + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
     int rc = lm_head_and_advance(ctx, slot0, nseq, 0, seq_len, s);
     if (rc) return rc;
+    if (ctx->prof) kev_end(ctx->kev[3], s);
     stage_end(ctx, stage, s);
     return AUR_OK;
 }
@@ -1240,7 +1270,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
         else if (!strcmp(name, "gemm_lab")) {
 #ifdef AUR_LABS
-            ctx->gemm_lab = (value >= 0 && value <= 8) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
+            ctx->gemm_lab = (value >= 0 && value <= 16) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
 #else
             return aur_fail(ctx, AUR_ERR_ARG, "gemm_lab exists in AUR_LABS builds only (python -m aurora_amd.build --labs)");
 #endif

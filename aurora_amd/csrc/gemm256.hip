@@ -23,6 +23,21 @@
 #include "gemm_epilogue.h"
 #include "tile_order.h"
 
+// Which phase of K-tile t issues which half-tile of LDS-DMA prefetch (all three keep the same issue ORDER A1(t+1), W0(t+2), W1(t+2),
+// A0(t+2), hence the same counted wait vmcnt(6) in phase 3 and the same arithmetic):
+//   0: one half-tile per phase - A1 | W0 | W1 | A0     (rounds 1-3)
+//   1: none | A1, W0 | W1, A0 | none                   the two read-heavy / waiting phases (0: 12 fragment reads, 3: the vmcnt wait) issue nothing
+//   2: none | A1, W0 | W1 | A0
+//   4: nothing in the load segments: the two instructions of a half-tile are issued INSIDE the phase's MFMA burst (after the 4th and the
+//      12th MFMA), A1 | W0 | W1 | A0 by phase - the per-CU LDS-DMA path takes one 1 KiB instruction per 16 cycles, and a burst of 8-16
+//      of them at the head of a load segment is what made the segment outlast the partner's burst; phase 3 then waits vmcnt(4)
+// Round 4 measured the segments (tools/gemm_lab/ts_probe.py, profiles/r04_gemm_segments.log): with schedule 0 the load segments of phases 0
+// and 3 outlast the partner group's 16-MFMA burst (329 / 222-287 cycles against 292) while phases 1 and 2 idle at the barrier.  An LDS-DMA
+// instruction costs its wave 60-90 cycles wherever it sits (in a load segment or between MFMAs: schedule 4 lengthens the bursts by what
+// it takes off the load segments); without any operand DMA the same kernel runs 1.28x faster - the price of feeding a 256 x 256 tile.
+#ifndef G2_SCHED
+#define G2_SCHED 2      // round 4: +3..6 % on every shape of the path against schedule 0 (profiles/r04_gemm_segments.log), same bits
+#endif
 // ---- lab instantiations (tools/cumask/contention_lab.py; never launched by the product path: GemmArgs.lab == 0 there).
 // TAG >= GT_LAB_BASE selects a deliberately altered kernel that answers "what does the front-end GEMM take away from a concurrent
 // decode stream?": cache-policy bits on the operand DMAs, no DMA at all (power / clock only), no MFMA (fabric traffic only), or the
@@ -37,10 +52,12 @@ template <int TAG> struct G2Lab {
 #endif
     static constexpr int aux_a = (id == 1 || id == 3) ? 2 : (id == 4 ? 16 : 0);     // 2 = nt, 16 = sc1
     static constexpr int aux_w = (id == 2 || id == 3) ? 2 : (id == 4 ? 16 : 0);
-    static constexpr bool no_dma = id == 5;
+    static constexpr bool no_dma = id == 5 || id == 14;
     static constexpr bool no_mfma = id == 6;
-    static constexpr bool a_tiled = id == 7;
-    static constexpr bool ts = id == 8;          // s_memtime stamps around every segment of every phase -> g2_ts (aur_lab_gemm_ts)
+    static constexpr bool a_tiled = id == 7 || id == 13;
+    // 8-10, 13, 14: s_memtime stamps around every segment of every phase -> g2_ts (aur_lab_gemm_ts); 9 / 11: DMA schedule 1, 10 / 12: 2
+    static constexpr bool ts = (id >= 8 && id <= 10) || id == 13 || id == 14 || id == 16;
+    static constexpr int sched = (id == 9 || id == 11) ? 1 : (id == 10 || id == 12) ? 2 : (id == 15 || id == 16) ? 4 : G2_SCHED;     // 15 / 16: schedule 4 without / with stamps
 };
 #ifdef AUR_LABS
 // lab 8: per workgroup and wave, cycles summed over the K loops of all its tiles, [phase 0..3][load segment, barrier 1, lgkmcnt wait,
@@ -109,6 +126,20 @@ __device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, 
     char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
     glds16x<G2Lab<TAG>::aux_w>(src.w[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
     glds16x<G2Lab<TAG>::aux_w>(src.w[h][1] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 1) * 1024);
+}
+// one of the two instructions of a half-tile (schedule 4 issues them inside the MFMA bursts)
+template <int TAG>
+__device__ __forceinline__ void g2_stage_a1(const G2Src& src, char* smem, int w, int h, int kt, int i) {
+    if constexpr (G2Lab<TAG>::no_dma) return;
+    char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
+    const int64_t step = G2Lab<TAG>::a_tiled ? (int64_t)kt * 256 * 64 : (int64_t)kt * 64;
+    glds16x<G2Lab<TAG>::aux_a>(src.a[h][i] + step, dst + (w * 2 + i) * 1024);
+}
+template <int TAG>
+__device__ __forceinline__ void g2_stage_w1(const G2Src& src, char* smem, int w, int h, int kt, int wb, int i) {
+    if constexpr (G2Lab<TAG>::no_dma) return;
+    char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
+    glds16x<G2Lab<TAG>::aux_w>(src.w[h][i] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + i) * 1024);
 }
 // prologue of a tile: K-tile 0 completely (8 instructions), plus W0, W1, A0 of K-tile 1 (6 instructions that may stay in flight)
 template <int TAG>
@@ -184,7 +215,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
             tCp = tC;                                                                                        \
         }                                                                                                    \
     } while (0)
-#define G2_COMPUTE(NH, MH, wf)                                                                                   \
+#define G2_COMPUTE(NH, MH, wf, D0, D1)                                                                           \
     do {                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         G2_TS_COLLECT(((NH) == 0 && (MH) == 0) ? 0 : ((NH) == 1 && (MH) == 0) ? 1 : ((NH) == 1 && (MH) == 1) ? 2 : 3); \
@@ -200,6 +231,11 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
                         acc[(NH) * 2 + tt][(MH) * 4 + uu] = mfma16(af[uu * 2 + kk], wf[tt * 2 + kk], acc[(NH) * 2 + tt][(MH) * 4 + uu]); \
                     else                                                                                     \
                         acc[(NH) * 2 + tt][(MH) * 4 + uu] = mfma16(wf[tt * 2 + kk], af[uu * 2 + kk], acc[(NH) * 2 + tt][(MH) * 4 + uu]); \
+                    if (G2Lab<TAG>::sched == 4 && uu == 3 && tt == 0) {                                      \
+                        __builtin_amdgcn_sched_barrier(0);                                                   \
+                        if (kk == 0) { D0; } else { D1; }                                                    \
+                        __builtin_amdgcn_sched_barrier(0);                                                   \
+                    }                                                                                        \
                 }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         G2_TS(tE);                                                                                           \
@@ -220,46 +256,50 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
         const char* wbuf = smem + G2_WBASE + wb * G2_WBUF;
         const int wb2 = wb == 0 ? 2 : wb - 1;              // (t + 2) % 3
         const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;     // block-uniform
+        constexpr int SCHED = G2Lab<TAG>::sched;
         // phase 0: quadrant (n half 0, m half 0)
         G2_TS(tA);
         read_a(abuf, 0);
         read_w(wbuf, 0, wf0);
-        if (n1) stage_a(1, t + 1);
+        if (SCHED == 0 && n1) stage_a(1, t + 1);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(0, 0, wf0);
+        G2_COMPUTE(0, 0, wf0, if (n1) g2_stage_a1<TAG>(src, smem, w, 1, t + 1, 0), if (n1) g2_stage_a1<TAG>(src, smem, w, 1, t + 1, 1));
         G2_BARRIER();
         // phase 1: (n half 1, m half 0)
         G2_TS(tA);
         read_w(wbuf, 1, wf1);
-        if (n2) stage_w(0, t + 2, wb2);
+        if (SCHED != 0 && SCHED != 4 && n1) stage_a(1, t + 1);
+        if (SCHED != 4 && n2) stage_w(0, t + 2, wb2);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(1, 0, wf1);
+        G2_COMPUTE(1, 0, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 0, t + 2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 0, t + 2, wb2, 1));
         G2_BARRIER();
         // phase 2: (n half 1, m half 1)
         G2_TS(tA);
         read_a(abuf, 1);
-        if (n2) stage_w(1, t + 2, wb2);
+        if (SCHED != 4 && n2) stage_w(1, t + 2, wb2);
+        if (SCHED == 1 && n2) stage_a(0, t + 2);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(1, 1, wf1);
+        G2_COMPUTE(1, 1, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 1, t + 2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 1, t + 2, wb2, 1));
         G2_BARRIER();
         // phase 3: (n half 0, m half 1); retire K-tile t+1's half-tiles, keep W0, W1, A0 of t+2 in flight
         G2_TS(tA);
         if (n2) {
-            stage_a(0, t + 2);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (SCHED != 1 && SCHED != 4) stage_a(0, t + 2);
+            if (SCHED == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W0, W1 of t+2 stay in flight; A0(t+2) follows in this phase's burst
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(0, 1, wf0);
+        G2_COMPUTE(0, 1, wf0, if (n2) g2_stage_a1<TAG>(src, smem, w, 0, t + 2, 0), if (n2) g2_stage_a1<TAG>(src, smem, w, 0, t + 2, 1));
         G2_BARRIER();
         wb = wb == 2 ? 0 : wb + 1;
     }
@@ -295,11 +335,12 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
 // half of activation buffer 1): the prologue's DMA is already in flight while this runs.
 #define G2_SLAB_STRIDE 272
 #define G2_SLAB_BYTES (16 * G2_SLAB_STRIDE)
-// One 16-row block (u) of the wave's 128 x 64 region.  U is a TEMPLATE parameter on purpose: rounds 2-3 wrote this as `#pragma unroll
-// for (int u ..)`, the body outgrew LLVM's pragma-unroll threshold, the loop stayed rolled, `acc[t][u]` became a runtime index and
-// hipcc moved the whole accumulator array to SCRATCH (528 B per lane: 32 zero stores + 32 stores + 32 loads of 1 KiB per wave and
-// tile, 512 KiB of scratch traffic per 128 KiB output tile; round 4 found it in the .s: `.private_segment_fixed_size 528`).  With a
-// compile-time U every accumulator index is static and the array stays in registers (tests/test_static_asm.py pins 0 bytes of scratch).
+// One 16-row block (u) of the wave's 128 x 64 region.  U is a TEMPLATE parameter on purpose: as `#pragma unroll for (int u ..)` the loop
+// sits at the edge of LLVM's pragma-unroll threshold - round 4's third activation branch (act_other_f) pushed the body over it, the loop
+// stayed rolled, `acc[t][u]` became a runtime index and hipcc moved the whole accumulator array to SCRATCH (`.private_segment_fixed_size
+// 528`: 32 + 32 stores and 32 loads of 1 KiB per wave and tile; ViT fc1 938 -> 590 TF/s, found in the .s and in tools/gemm_probe.py before
+// it shipped).  With a compile-time U every accumulator index is static whatever the body grows to (tests/test_static_asm.py pins 0
+// bytes of scratch for every kernel of this file).
 template <int U>
 __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], int mb, int nb, int lane, char* slab) {
     const int r = lane & 15, g = lane >> 4;
@@ -464,7 +505,11 @@ hipError_t gemm256_init() {
     if ((e = g2_attr<EPI_ROW, GT_LAB_BASE + 1>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 2>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 3>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 4>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 5>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 6>()) != hipSuccess ||
-        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 8>()) != hipSuccess)
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 7>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 8>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 9>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 10>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 11>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 12>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 13>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 14>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 15>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 16>()) != hipSuccess)
         return e;
 #endif
     return hipSuccess;
@@ -498,6 +543,14 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 6: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 6); break;
             case 7: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 7); break;
             case 8: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 8); break;
+            case 9: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 9); break;
+            case 10: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 10); break;
+            case 11: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 11); break;
+            case 12: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 12); break;
+            case 13: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 13); break;
+            case 14: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 14); break;
+            case 15: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 15); break;
+            case 16: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 16); break;
             default: return hipErrorInvalidValue;
         }
 #endif

@@ -472,6 +472,7 @@ def main():
         torch.cuda.synchronize()
 
     out = None
+    serving_split = None
     NG, S = (B // G if B % G == 0 else 0), N - 1                   # groups of G slots; decode steps per caption after its prefill
     continuous = not (args.batch_mode or pipe or args.decode_chunk > 0) and NG >= 2 and N >= 2 * NG
     batch_ref = None
@@ -579,6 +580,7 @@ def main():
             if args.gemm_cus <= 0:
                 eng.set_option("gemm_max_wgs", 8 * fc)
             pending = [None]
+            stage_ev = []
 
             # host-observed TTFT ("submit -> first generated token id on host"): the host clock from the moment a group's
             # front end is submitted to the moment its first token ids have landed in pinned host memory.  A side stream waits for the
@@ -629,27 +631,34 @@ def main():
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(sF)
                     vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
+                    ev_v = torch.cuda.Event(enable_timing=True)
+                    ev_v.record(sF)
                     for j in range(G):
                         eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+                    ev_p = torch.cuda.Event(enable_timing=True)
+                    ev_p.record(sF)
                     eng.prefill_stage(B, G, emb_all, L0)
-                    evf = torch.cuda.Event(enable_timing=k_cal["on"])
+                    evf = torch.cuda.Event(enable_timing=True)
                     evf.record(sF)
                 if k_cal["on"]:
                     k_cal["front_ev"].append((e0, evf))
                 front_seq[0] += 1
                 start_q.put((front_seq[0], e0))
-                return e0, evf, (front_seq[0], t_host)
+                return e0, evf, (front_seq[0], t_host), (ev_v, ev_p)
 
             def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
                 for g in range(NG):
                     eng.slot_collect(g * G, G, ids_out[g], len_out[g])
-                    e0, evf, t_host = pending[0]
+                    e0, evf, t_host, (ev_v, ev_p) = pending[0]
                     sD.wait_event(evf)
+                    ec0 = torch.cuda.Event(enable_timing=True)
+                    ec0.record(sD)                                  # the decode stream has reached the group's boundary AND the front end is done
                     eng.prefill_commit(g * G, G, B, emb_all, L0)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(sD)
                     if timed:
                         lat_ev.append((e0, e1))
+                        stage_ev.append((e0, ev_v, ev_p, evf, ec0, e1))
                         with torch.cuda.stream(sC):
                             sC.wait_event(e1)
                             eng.slot_collect(g * G, G, first_dev[g], first_len[g])
@@ -718,6 +727,14 @@ def main():
         if overlap and args.gemm_cus <= 0:
             eng.set_option("gemm_max_wgs", 0)                      # the instrumented pass below runs alone on the whole GPU
         ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
+        if overlap and stage_ev:
+            med = lambda i, j: float(np.median([ev[i].elapsed_time(ev[j]) for ev in stage_ev]))
+            serving_split = {"vit_and_tome": med(0, 1), "projector_splice": med(1, 2), "prefill_layers": med(2, 3),
+                             "commit_wait": med(3, 4), "lm_head_argmax_commit": med(4, 5), "total": med(0, 5),
+                             "note": "medians over the timed cycles' groups of %d clips, device events: the front-end stream (16 CUs of every XCD, beside the "
+                                     "masked decode) runs ViT + ToMe, projector + splice and the staged prefill layer stack; `commit_wait` is the time the "
+                                     "finished front end waits for the decode stream to reach the group's boundary; the commit (decode stream) swaps the "
+                                     "page-table rows and produces the first tokens" % G}
         if overlap:
             host_q.put(None)
             start_q.put(None)
@@ -979,6 +996,13 @@ def main():
             result["roofline_step"] = {"ideal_ms": 1e3 * ideal_s, "measured_ms": result["ms_per_step"], "frac": 1e3 * ideal_s / result["ms_per_step"],
                                        "model": "decode: weights once per step + K/V of every cached token, at 8 TB/s; ViT, projector and prefill "
                                                 "flops at 2.5 PFLOP/s (SURVEY 8d)"}
+            # the stricter bound for a schedule that OVERLAPS the two resources (the default one does): the slower of the HBM-bound decode and
+            # the MFMA-bound front ends, not their sum (quoted beside the sum model)
+            hbm_s, mfma_s = dec_bytes / 8e12, B * (pre_fl + vit_fl + proj_fl) / 2.5e15
+            result["roofline_step_overlap"] = {"ideal_ms": 1e3 * max(hbm_s, mfma_s), "measured_ms": result["ms_per_step"],
+                                               "frac": 1e3 * max(hbm_s, mfma_s) / result["ms_per_step"], "hbm_ms": 1e3 * hbm_s, "mfma_ms": 1e3 * mfma_s,
+                                               "model": "max(decode bytes at 8 TB/s, front-end flops at 2.5 PFLOP/s): what a schedule that overlaps "
+                                                        "the two perfectly would take; the chip cannot hold both peaks at once (1400 W socket cap, DESIGN section 4)"}
         # single-clip latency (batch 1): TTFT without queueing behind other clips' ViT/prefill
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -993,6 +1017,21 @@ def main():
             torch.cuda.synchronize()
             lat.append(e0.elapsed_time(e1))
         result["ttft_ms_single_clip"] = float(np.median(lat))
+        # where a single clip's time to first token goes: one more pass with the stage timers on
+        eng.profile(True)
+        vis = eng.vit_encode(pixels[:F], r)
+        eng.begin_batch(1, N, None)
+        emb, L = eng.project_splice(vis, ids[0])
+        eng.prefill(0, emb, L)
+        torch.cuda.synchronize()
+        st1 = {k: eng.profile_read(k)[0] for k in ("vit", "vit_tome", "project", "prefill", "first_token")}
+        eng.profile(False)
+        result["ttft_stage_ms"] = {
+            "single_clip": {"vit_without_tome": st1["vit"] - st1["vit_tome"], "tome": st1["vit_tome"], "projector_splice": st1["project"],
+                            "prefill_layers": st1["prefill"] - st1["first_token"], "lm_head_argmax": st1["first_token"],
+                            "sum": st1["vit"] + st1["project"] + st1["prefill"],
+                            "note": "one clip alone on the whole GPU, stage timers (HIP events) of one extra pass; ToMe = the three launches per layer"},
+            "serving": serving_split}
         hl = []
         for _ in range(3):                                            # the same, on the host clock, including the read-back of the slot state
             torch.cuda.synchronize()

@@ -364,3 +364,33 @@ def test_full_size_cfg3_and_cfg5_at_their_own_ratios(name, frames, ratio, kept):
         assert [got[i] for i in range(3)] == alone + alone[:1]
     finally:
         eng.close()
+
+
+def test_full_size_configs3_per_gpu_share_eight_clips_in_one_batch():
+    """BASELINE configs[3]'s per-GPU workload (`bench.py --gpus 8 --config cfg4`): EIGHT cfg2 clips (8 frames, ratio 0.3, prefix 2142) in
+    ONE batch of an 8-slot engine at full model size, 256 new tokens - the regime where the decode step is the weight stream, not K / V
+    (decode attention runs 2 splits per (sequence, head); the projections take the per-wave-x structure of engines <= 32 slots).
+    Properties: the batch == each of its clips alone (two of them are re-run alone in full), a repeat of the batch is bit-identical,
+    every clip yields exactly 256 ids inside the vocabulary and the eight captions are distinct; clip i of rank k of the 8-rank job is
+    clip k + 8 i (round-robin shard) - the batch below is rank 3's."""
+    from aurora_amd import parallel
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine
+    cfg = S.AURORACAP_7B
+    w = {"vit": S.vit_weights(cfg["vit"]), "projector": S.projector_weights(1280, 4096), "llm": S.llm_weights(cfg["llm"])}
+    N, L0 = 256, 30 + 8 * 264
+    eng = AuroraCapEngine(cfg, w, max_frames=8 * 8, max_batch=8, max_ctx=-(-(L0 + N) // 64) * 64, max_new_tokens=N)
+    del w
+    torch.cuda.empty_cache()
+    try:
+        mine = parallel.shard_clips(64, 3, 8)
+        assert mine == [3, 11, 19, 27, 35, 43, 51, 59]
+        clips = [(S.frames(8, c), S.prompt_ids(8, c)) for c in mine]
+        batch = eng.caption_batch(clips, 0.3, N, eos_id=None)
+        assert len(batch) == 8 and all(len(o) == N and all(0 <= t < 32000 for t in o) for o in batch)
+        assert len({tuple(o) for o in batch}) == 8
+        assert eng.caption_batch(clips, 0.3, N, eos_id=None) == batch                 # repeatable, graph replays included
+        for j in (0, 5):                                                               # batch == alone, all 256 tokens
+            assert eng.caption_ids(clips[j][0], clips[j][1], 0.3, N, eos_id=None) == batch[j]
+    finally:
+        eng.close()

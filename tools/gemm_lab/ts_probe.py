@@ -30,10 +30,11 @@ def main():
     L.aur_lab_gemm_ts.argtypes = [C.c_void_p, C.c_int]
     g = torch.Generator(device="cuda").manual_seed(0)
     ts = np.zeros(256 * 8 * 24, dtype=np.uint32)
+    STAMPED = (8, 9, 10, 13, 14, 16)
 
     def run(name, M, K, N, lab, iters=8):
         npad = _rup(N, 256)
-        a = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+        a = (torch.randn(_rup(M, 256), K, generator=g, device="cuda") * 0.5).half()      # whole 256-row tiles: lab 13 reads a K-tile-major image of them
         w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
         wp = eng.pack(w, npad, K)
         bias = torch.zeros(npad, device="cuda")
@@ -54,7 +55,8 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         print(f"\n{name}: M {M} K {K} N {N} lab {lab}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
-        if lab != 8:
+        if lab not in STAMPED:
+            eng.set_option("gemm_lab", 0)
             return
         assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
         t = ts.reshape(256, 8, 24).astype(np.float64)
@@ -70,10 +72,17 @@ def main():
                 print(f"    {p}     " + " ".join(f"{v:6.0f}" for v in seg[p]) + f" {seg[p].sum():6.0f}")
         eng.set_option("gemm_lab", 0)
 
-    for lab in (0, 8):
-        run("llm gate/up, 4-clip prefill pass", 8576, 4096, 22016, lab)
-    for lab in (0, 8):
-        run("vit fc1, t = 640 x 32 frames", 20480, 1280, 5120, lab)
+    print("labs: 0 product | 11 / 12 / 15 DMA schedule 1 / 2 / 4 (no stamps) | 8 / 9 / 10 / 16 stamps on schedule 0 / 1 / 2 / 4 | 13 stamps + A from a "
+          "K-tile-major image | 14 stamps + no operand DMA")
+    shapes = [("llm gate/up, 4-clip prefill pass", 8576, 4096, 22016), ("llm down", 8576, 11008, 4096), ("llm qkv-shaped", 8576, 4096, 12288),
+              ("vit fc1, t = 640 x 32 frames", 20480, 1280, 5120), ("vit fc2", 20480, 5120, 1280)]
+    for rep in range(3):                                            # interleaved A/B/A/B of the un-stamped kernels
+        for name, M, K, N in shapes:
+            for lab in (0, 12, 15):
+                run(name, M, K, N, lab)
+    for name, M, K, N in shapes[:1] + shapes[3:4]:
+        for lab in (8, 10, 16):
+            run(name, M, K, N, lab)
     eng.close()
 
 
