@@ -80,6 +80,7 @@ struct aur_ctx {
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
+    int skinny_variant_wide = 0;                                                // the same choice for the two WIDE projections (QKV, gate/up): x through LDS from 8 slots up
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
@@ -203,6 +204,10 @@ static void derive(aur_ctx* c) {
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
     c->nbanks = g.num_banks == 2 ? 2 : 1;
     c->skinny_variant = g.max_batch > 32 ? 1 : 0;        // a function of the engine's capacity, never of the live batch
+    // QKV and gate/up (N = 12288 / 22016: several tiles per CU share x) gain from x-through-LDS already at 8 slots - 22.6 -> 20.4 us and
+    // 33.3 -> 31.6 us at 8 rows (round 4, tools/microbench.py --batch 8: configs[3]'s per-GPU engine) - while o / down / lm_head do not
+    // (9.1 / 19.0 / 46.0 us either way or worse).  Also a function of the capacity only.
+    c->skinny_variant_wide = g.max_batch >= 8 ? 1 : c->skinny_variant;
     c->kv_seqs = g.max_batch + (g.spare_slots > 0 ? g.spare_slots : 0);     // KV sequences per bank: decode slots + spare prefill targets
     c->l_layer_halves = c->l_page_halves * c->l_max_pages * c->kv_seqs * c->nbanks;
     // decode attention: one wave per (sequence, head, split).  Enough splits to put ~512 waves on the GPU for small batches,
@@ -1094,7 +1099,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant; q.ring = ctx->skinny_ring;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant_wide; q.ring = ctx->skinny_ring;
     q.half_grid = ctx->decode_half;
     return q;
 }
@@ -1121,7 +1126,7 @@ static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     SkinnyArgs gu{};
     gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
     gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
-    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant; gu.ring = ctx->skinny_ring;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant_wide; gu.ring = ctx->skinny_ring;
     gu.gu_ks = g.max_batch > 64 ? 1 : 2; gu.half_grid = ctx->decode_half;
     return gu;
 }
@@ -1257,7 +1262,8 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     }
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
     else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
-    else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = value ? 1 : 0;
+    else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = ctx->skinny_variant_wide = value ? 1 : 0;
+    else if (!strcmp(name, "skinny_variant_wide")) ctx->skinny_variant_wide = value ? 1 : 0;
     else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strncmp(name, "gemm_", 5) || !strcmp(name, "microbench_prefill_nseq")) {

@@ -518,10 +518,15 @@ hipError_t gemm256_init() {
 int gemm256_grid_cap() { return g_gemm256_cus & ~7; }
 
 bool gemm256_eligible(const GemmArgs& a) {
-    // whole 256-column tiles, and enough 256x256 tiles to fill the 256 CUs at one workgroup each
+    // whole 256-column tiles, and more 256x256 tiles than HALF of the persistent grid G (one 160 KiB workgroup per CU; max_wgs under a
+    // CU mask).  Cost model in rounds of the 128x128 kernel (2 workgroups per CU, measured 1.3-1.5x slower per flop): ceil(T / G) x ~1.4
+    // against ceil(2 T / G) x 1 - the big tile wins as soon as the small one needs a second round.  Rounds 1-3 asked for T >= 224 and sent
+    // the o / down projections of a single-clip prefill (144 tiles) to the 128x128 kernel: 116 / 296 us against 98 / 229 us (round 4,
+    // tools/microbench.py --batch 8), 2.7 ms of a 50 ms time to first token.  The two kernels agree bit for bit, so this is speed only.
     if (a.Npad & 255) return false;
     const int64_t tiles = (int64_t)(a.Npad >> 8) * ((a.M + 255) >> 8);
-    return tiles >= 224;
+    const int G = a.max_wgs > 0 ? ((a.max_wgs + 7) & ~7) : (g_gemm256_cus & ~7);
+    return 2 * tiles > G;
 }
 
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
