@@ -80,7 +80,7 @@ struct aur_ctx {
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
-    int skinny_variant_wide = 0;                                                // the same choice for the two WIDE projections (QKV, gate/up): x through LDS from 8 slots up
+    int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
@@ -204,10 +204,10 @@ static void derive(aur_ctx* c) {
     c->l_page_halves = (int64_t)2 * g.llm_heads * g.page_tokens * c->l_hd;
     c->nbanks = g.num_banks == 2 ? 2 : 1;
     c->skinny_variant = g.max_batch > 32 ? 1 : 0;        // a function of the engine's capacity, never of the live batch
-    // QKV and gate/up (N = 12288 / 22016: several tiles per CU share x) gain from x-through-LDS already at 8 slots - 22.6 -> 20.4 us and
-    // 33.3 -> 31.6 us at 8 rows (round 4, tools/microbench.py --batch 8: configs[3]'s per-GPU engine) - while o / down / lm_head do not
-    // (9.1 / 19.0 / 46.0 us either way or worse).  Also a function of the capacity only.
-    c->skinny_variant_wide = g.max_batch >= 8 ? 1 : c->skinny_variant;
+    // QKV and gate/up (N = 12288 / 22016: several tiles per CU share x) gain from x-through-LDS at EVERY capacity - 22.3-22.9 -> 20.4-20.8 us
+    // and 33.3-33.8 -> 31.6-31.9 us at 1, 4 and 8 rows (round 4, tools/microbench.py --batch 1 / 4 / 8) - while o / down do not (9.1 /
+    // 19.0-19.5 us either way or worse).  configs[3]'s per-GPU engine (8 slots): 5.80 -> 6.01 captions/s with this and the GEMM changes.
+    c->skinny_variant_wide = 1;
     c->kv_seqs = g.max_batch + (g.spare_slots > 0 ? g.spare_slots : 0);     // KV sequences per bank: decode slots + spare prefill targets
     c->l_layer_halves = c->l_page_halves * c->l_max_pages * c->kv_seqs * c->nbanks;
     // decode attention: one wave per (sequence, head, split).  Enough splits to put ~512 waves on the GPU for small batches,

@@ -329,3 +329,56 @@ def test_tome_match_hand_over_stress_alone_and_beside_a_decode_stream():
         torch.cuda.synchronize()
     finally:
         eng.close()
+
+
+def test_tome_hand_over_beside_the_real_decode_graph_on_cu_masked_streams():
+    """ADVICE r3 (medium) / VERDICT r3 item 2: the ToMe match -> select hand-over stressed in the SERVING arrangement, not beside a
+    synthetic `add_`: the ViT-H encoder (31 ToMe steps per pass, 32 frames) runs on the front-end stream (16 CUs of every XCD) while the
+    captured decode step of a 128-slot engine (real widths: K / V stream of 128 x 2.1k tokens, 4096-wide projections) replays on the
+    other 16.  `hidden_states[-2]` depends on every layer's indices bit for bit, so one stale read in ~16 k hand-overs (16 passes x 31
+    layers x 32 frames) would change the features: every pass must equal the pass taken alone.
+    (Round 3's fused split-K reduce failed in exactly this arrangement; its cause was an unpadded inline-asm store hazard, not the
+    arrival protocol - profiles/r04_fused_reduce_rootcause.txt - and tome_match_kernel's stores are compiler-emitted.)"""
+    from aurora_amd import synthetic as S
+    from aurora_amd.engine import AuroraCapEngine, _rup
+    from aurora_amd.streams import shared_cu_masked_stream
+    v = S.AURORACAP_7B["vit"]
+    l = dict(S.AURORACAP_7B["llm"], num_hidden_layers=2)
+    w = {"vit": S.vit_weights(v), "llm": S.llm_weights(l, num_layers=2)}
+    B, L0, N = 128, 2142, 768
+    eng = AuroraCapEngine({"vit": v, "llm": l}, w, max_frames=32, max_batch=B, max_ctx=_rup(L0 + N, 64), max_new_tokens=N)
+    del w
+    torch.cuda.empty_cache()
+    try:
+        px = torch.cat([S.frames(8, 70 + i) for i in range(4)], 0)
+        r = eng.tome_r(0.3)
+        ref = eng.vit_encode(px, r).clone()
+        assert tuple(ref.shape) == (32, 264, 1280)
+        assert torch.equal(eng.vit_encode(px, r), ref)                         # repeatable alone
+        eng.begin_batch(B, N, None)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        emb = (torch.randn(4 * _rup(L0, 32), l["hidden_size"], generator=gen, device="cuda") * 0.02).half()
+        for b0 in range(0, B, 4):
+            eng.prefill_batch(b0, 4, emb.clone(), L0)
+        torch.cuda.synchronize()
+        sF, sD = shared_cu_masked_stream(16, device=eng.dev), shared_cu_masked_stream(16, from_top=True, device=eng.dev)
+        cur = torch.cuda.current_stream()
+        sF.wait_stream(cur)
+        sD.wait_stream(cur)
+        with torch.cuda.stream(sD):
+            eng.decode(N - 1)                                                  # ~1.5 s of graph replays on the top 16 CUs of every XCD
+            done = torch.cuda.Event()
+            done.record(sD)
+        outs = []
+        eng.set_option("gemm_max_wgs", 128)
+        with torch.cuda.stream(sF):
+            for _ in range(16):
+                outs.append(eng.vit_encode(px, r).clone())
+            overlapped = not done.query()                                      # the decode was still running when the last pass was enqueued
+        torch.cuda.synchronize()
+        eng.set_option("gemm_max_wgs", 0)
+        assert overlapped
+        for i, o in enumerate(outs):
+            assert torch.equal(o, ref), f"pass {i} beside the decode graph differs from the pass alone"
+    finally:
+        eng.close()
