@@ -84,12 +84,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return row16_max(v);
 }
 
-// x * sigmoid(k x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction IEEE division: these run 128 times
-// per lane in the epilogue of every 256x256 MLP tile (measured 6.8 us of a 40 us ViT fc1 tile with the IEEE form); the outputs are
-// rounded to fp16 right after, 13 bits above the difference.
-__device__ __forceinline__ float quick_gelu_f(float x) { return __fdividef(x, 1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(k x) with the hardware reciprocal and base-2 exponential: v_mul, v_exp_f32, v_add, v_rcp_f32 (1 ulp), v_mul - five
+// instructions.  (Rounds 2-3 wrote `__fdividef(x, 1 + __expf(..))` believing it lowered to v_rcp_f32; round 4 read the ISA: without
+// -ffast-math hipcc expands it to the full IEEE sequence - v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup - ~16 instructions per
+// element, 128 elements per lane in the epilogue of every 256x256 MLP tile, which is VALU-issue-bound: tools/gemm_lab/ts_probe.py.)
+// The outputs are rounded to fp16 right after, 13 bits above the reciprocal's last-ulp difference.
+__device__ __forceinline__ float sigmoid_scaled_f(float x, float k_log2e) {      // 1 / (1 + exp(-k x)), k_log2e = k * log2(e)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-k_log2e * x));
+}
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_scaled_f(x, 2.4554669595930157f); }     // 1.702 * log2(e)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_scaled_f(x, 1.4426950408889634f); }
 // the activations a ProjectorConfig.hidden_act may name besides the two above (act = ACT_SILU / ACT_RELU / ACT_GELU_TANH, kernels.h); one
 // uniform branch per element behind the two common cases, never on the ViT / Llama path
 __device__ __forceinline__ float act_other_f(float x, int act) {

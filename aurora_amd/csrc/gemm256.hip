@@ -35,6 +35,17 @@
 // and 3 outlast the partner group's 16-MFMA burst (329 / 222-287 cycles against 292) while phases 1 and 2 idle at the barrier.  An LDS-DMA
 // instruction costs its wave 60-90 cycles wherever it sits (in a load segment or between MFMAs: schedule 4 lengthens the bursts by what
 // it takes off the load segments); without any operand DMA the same kernel runs 1.28x faster - the price of feeding a 256 x 256 tile.
+// Start-up stagger of the persistent workgroups (0 = none; S = S slots per XCD).  All tiles of a GEMM take the same time, so without it
+// every CU reaches its epilogue at the same moment and 256 x 128 KiB of output hit the memory system in one burst: round 4 measured the
+// epilogue at 38-46 k cycles per tile whatever the activation (tools/gemm_lab/ts_probe.py) = 3.4 B per cycle per CU = HBM's write rate,
+// while the K loops around it leave HBM idle.  Workgroup b sleeps ((b / 8) % S) / S of a tile's duration before its first tile: epilogues
+// of some CUs then overlap K loops of others.
+#ifndef G2_CONT
+#define G2_CONT 0      // 1 = continuous pipeline across tile boundaries (g2_mainloop): built and bit-exact in round 4, measured 1-2 % SLOWER than
+#endif                 //     the per-tile prologue (profiles/r04_gemm_segments.log: the prologue burst was not what the epilogue waits for) - off
+#ifndef G2_STAGGER
+#define G2_STAGGER 0
+#endif
 #ifndef G2_SCHED
 #define G2_SCHED 2      // round 4: +3..6 % on every shape of the path against schedule 0 (profiles/r04_gemm_segments.log), same bits
 #endif
@@ -56,14 +67,20 @@ template <int TAG> struct G2Lab {
     static constexpr bool no_mfma = id == 6;
     static constexpr bool a_tiled = id == 7 || id == 13;
     // 8-10, 13, 14: s_memtime stamps around every segment of every phase -> g2_ts (aur_lab_gemm_ts); 9 / 11: DMA schedule 1, 10 / 12: 2
-    static constexpr bool ts = (id >= 8 && id <= 10) || id == 13 || id == 14 || id == 16;
-    static constexpr int sched = (id == 9 || id == 11) ? 1 : (id == 10 || id == 12) ? 2 : (id == 15 || id == 16) ? 4 : G2_SCHED;     // 15 / 16: schedule 4 without / with stamps
+    static constexpr bool ts = (id >= 8 && id <= 10) || id == 13 || id == 14 || id == 16 || id == 19 || id == 20 || id == 21 || id == 23 || id == 24;
+    static constexpr bool cont = (G2_CONT != 0 || id == 22 || id == 23);   // 22 / 23 (= with stamps): the continuous pipeline
+    static constexpr bool wide_only = id == 24;        // stamps + the direct epilogue compiled OUT (a 30 KB kernel instead of 127 KB: instruction-cache probe)
+    static constexpr bool epi_nostore = id == 20;      // stamps + the wide epilogue without its global stores (where do its cycles go?)
+    static constexpr bool epi_halfstore = id == 21;    // stamps + NO LDS transposition in the wide epilogue (garbage output; both stores stay)
+    static constexpr int sched = (id == 9 || id == 11) ? 1 : (id == 10 || id == 12 || id >= 17) ? 2 : (id == 15 || id == 16) ? 4 : G2_SCHED;     // 15 / 16: schedule 4 without / with stamps
+    // 17 / 18: workgroups of one XCD start 0 .. 3/4 (17, 19 = with stamps) or 0 .. 7/8 (18) of a tile's duration apart
+    static constexpr int stagger = (id == 17 || id == 19) ? 4 : id == 18 ? 8 : G2_STAGGER;
 };
 #ifdef AUR_LABS
 // lab 8: per workgroup and wave, cycles summed over the K loops of all its tiles, [phase 0..3][load segment, barrier 1, lgkmcnt wait,
 // MFMA burst, barrier 2], then [20] = phases timed, [21] = total cycles of the K loops.  Stamps are s_memtime (SMEM: counted by lgkmcnt)
 // issued WITHOUT a wait of their own: they are collected behind the schedule's existing s_waitcnt lgkmcnt(0).
-__device__ unsigned g2_ts[256 * 8 * 24];
+__device__ unsigned g2_ts[256 * 8 * 32];     // + [22] tile head + K loop, [23] next tile's prologue issue, [24] epilogue, [25] tiles (cycles per wave)
 #endif
 template <int AUX>
 __device__ __forceinline__ void glds16x(const void* gsrc_lane, void* lds_wave_base) {
@@ -94,7 +111,7 @@ struct G2Src {
     const half_t* w[2][2];
 };
 template <int TAG>
-__device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, int w, int lane, G2Src& src) {
+__device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, int w, int lane, G2Src& src, bool do_a0 = true, bool do_a1 = true, bool do_w = true) {
     const int K32 = a.K >> 5;
     const int m0 = bm * 256;
 #pragma unroll
@@ -106,22 +123,26 @@ __device__ __forceinline__ void g2_sources(const GemmArgs& a, int bm, int bn, in
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             int m = m0 + h * 128 + row;
             m = m < a.M ? m : a.M - 1;
-            if constexpr (G2Lab<TAG>::a_tiled) src.a[h][i] = a.A + ((int64_t)bm * (a.K >> 6) * 256 + h * 128 + row) * 64 + c * 8;
-            else src.a[h][i] = a.A + (int64_t)m * a.lda + c * 8;
+            if (h == 0 ? do_a0 : do_a1) {                  // block-uniform
+                if constexpr (G2Lab<TAG>::a_tiled) src.a[h][i] = a.A + ((int64_t)bm * (a.K >> 6) * 256 + h * 128 + row) * 64 + c * 8;
+                else src.a[h][i] = a.A + (int64_t)m * a.lda + c * 8;
+            }
             const int f = grp;                      // fragment of the half-tile: n16 = f >> 1, kk = f & 1
-            src.w[h][i] = a.W + ((int64_t)(bn * 16 + h * 8 + (f >> 1)) * K32 + (f & 1)) * AUR_FRAG_HALVES + lane * 8;
+            if (do_w) src.w[h][i] = a.W + ((int64_t)(bn * 16 + h * 8 + (f >> 1)) * K32 + (f & 1)) * AUR_FRAG_HALVES + lane * 8;
         }
 }
+// kt = K-tile of the SOURCE tile, ab / wb = the LDS buffer it lands in.  Inside a tile buffer = (kt + phase) mod 2 / mod 3; the phases
+// carry over from tile to tile (continuous pipeline, gemm256_kernel), so source index and buffer are separate arguments.
 template <int TAG>
-__device__ __forceinline__ void g2_stage_a(const G2Src& src, char* smem, int w, int h, int kt) {
+__device__ __forceinline__ void g2_stage_a(const G2Src& src, char* smem, int w, int h, int kt, int ab) {
     if constexpr (G2Lab<TAG>::no_dma) return;
-    char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
+    char* dst = smem + ab * G2_ABUF + h * G2_SLOT;
     const int64_t step = G2Lab<TAG>::a_tiled ? (int64_t)kt * 256 * 64 : (int64_t)kt * 64;
     glds16x<G2Lab<TAG>::aux_a>(src.a[h][0] + step, dst + (w * 2 + 0) * 1024);
     glds16x<G2Lab<TAG>::aux_a>(src.a[h][1] + step, dst + (w * 2 + 1) * 1024);
 }
 template <int TAG>
-__device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, int h, int kt, int wb) {       // wb = kt % 3
+__device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, int h, int kt, int wb) {
     if constexpr (G2Lab<TAG>::no_dma) return;
     char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
     glds16x<G2Lab<TAG>::aux_w>(src.w[h][0] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + 0) * 1024);
@@ -129,9 +150,9 @@ __device__ __forceinline__ void g2_stage_w(const G2Src& src, char* smem, int w, 
 }
 // one of the two instructions of a half-tile (schedule 4 issues them inside the MFMA bursts)
 template <int TAG>
-__device__ __forceinline__ void g2_stage_a1(const G2Src& src, char* smem, int w, int h, int kt, int i) {
+__device__ __forceinline__ void g2_stage_a1(const G2Src& src, char* smem, int w, int h, int kt, int ab, int i) {
     if constexpr (G2Lab<TAG>::no_dma) return;
-    char* dst = smem + (kt & 1) * G2_ABUF + h * G2_SLOT;
+    char* dst = smem + ab * G2_ABUF + h * G2_SLOT;
     const int64_t step = G2Lab<TAG>::a_tiled ? (int64_t)kt * 256 * 64 : (int64_t)kt * 64;
     glds16x<G2Lab<TAG>::aux_a>(src.a[h][i] + step, dst + (w * 2 + i) * 1024);
 }
@@ -141,29 +162,42 @@ __device__ __forceinline__ void g2_stage_w1(const G2Src& src, char* smem, int w,
     char* dst = smem + G2_WBASE + wb * G2_WBUF + h * G2_SLOT;
     glds16x<G2Lab<TAG>::aux_w>(src.w[h][i] + (int64_t)kt * 2 * AUR_FRAG_HALVES, dst + (w * 2 + i) * 1024);
 }
-// prologue of a tile: K-tile 0 completely (8 instructions), plus W0, W1, A0 of K-tile 1 (6 instructions that may stay in flight)
+// prologue of a workgroup's FIRST tile (and of every tile when the K loop is too short for the continuous pipeline): K-tile 0 completely
+// (8 instructions) into A buffer 0 / W buffer 0, plus W0, W1, A0 of K-tile 1 (6 instructions that may stay in flight) into W buffer 1 /
+// A buffer 1 - buffer phases (0, 0)
 template <int TAG>
 __device__ __forceinline__ void g2_prologue(const GemmArgs& a, const G2Src& src, char* smem, int w) {
-    g2_stage_a<TAG>(src, smem, w, 0, 0);
-    g2_stage_a<TAG>(src, smem, w, 1, 0);
+    g2_stage_a<TAG>(src, smem, w, 0, 0, 0);
+    g2_stage_a<TAG>(src, smem, w, 1, 0, 0);
     g2_stage_w<TAG>(src, smem, w, 0, 0, 0);
     g2_stage_w<TAG>(src, smem, w, 1, 0, 0);
     if ((a.K >> 6) > 1) {
         g2_stage_w<TAG>(src, smem, w, 0, 1, 1);
         g2_stage_w<TAG>(src, smem, w, 1, 1, 1);
-        g2_stage_a<TAG>(src, smem, w, 0, 1);
+        g2_stage_a<TAG>(src, smem, w, 0, 1, 1);
     }
 }
 
-// K loop of one tile.  On entry the tile's prologue has been ISSUED (g2_prologue); `first` = nothing else is in flight, so the
-// counted wait of the original prologue applies; otherwise the previous tile's epilogue stores are in flight behind the DMAs and
-// the wait drains everything (stores and loads share vmcnt).
+// K loop of one tile.
+// CONTINUOUS PIPELINE (round 4, compile-time option G2_CONT, OFF: see the define).  The default flow issues the next tile's prologue (3.5
+// K-tiles' worth of LDS-DMA, 112 KiB per CU) in one burst after the K loop; the hypothesis was that the epilogue's first load - or a
+// spilled scalar's reload - waits behind that burst with vmcnt(0).  With G2_CONT the LAST TWO K-tiles of a tile stage the NEXT tile's
+// K-tiles 0 and 1 exactly where a middle K-tile stages t + 1 / t + 2:
+// same issue order, same counted waits, the LDS buffer rotation (ap: A buffer of K-tile 0, wp: W buffer of K-tile 0) simply carries over
+// the tile boundary, and phase 3 of the last K-tile retires the next tile's K-tile 0 like any other.  The source pointers are switched
+// to the next tile IN PLACE (W and A0 at K-tile nkt - 2, A1 at nkt - 1: the current tile no longer needs them), so no registers are
+// added.  Result: bit-exact (the whole kernel suite passes on it), the prologue burst is gone from the profile - and the epilogue still
+// takes its 30 k cycles (3.5 k per 16-row block with or without stores, LDS transposition or a small code footprint: labs 20 / 21 / 24),
+// while the K loop pays ~4 % for the extra branches.  Kept as a measured option, not the default.
+// `wait` = what to wait for on entry: 0 the first tile's prologue (counted), 1 drain everything (short K loops keep the old
+// per-tile prologue), 2 nothing (the previous tile's loop already retired this tile's K-tile 0).
 template <int EPI, bool VMODE, int TAG>
-__device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src, char* smem, f4 (&acc)[4][8], int w, int lane, bool first) {
+__device__ __forceinline__ void g2_mainloop(const GemmArgs& a, G2Src& src, char* smem, f4 (&acc)[4][8], int w, int lane, int wait, int ap, int wp,
+                                            bool has_next, int bm2, int bn2) {
     const int wr = w >> 2, wc = w & 3;
     const int r = lane & 15, g = lane >> 4;
     const int nkt = a.K >> 6;
-    auto stage_a = [&](int h, int kt) { g2_stage_a<TAG>(src, smem, w, h, kt); };
+    auto stage_a = [&](int h, int kt, int ab) { g2_stage_a<TAG>(src, smem, w, h, kt, ab); };
     auto stage_w = [&](int h, int kt, int wb) { g2_stage_w<TAG>(src, smem, w, h, kt, wb); };
 
     // fragment read offsets inside a buffer
@@ -244,53 +278,58 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
     } while (0)
 
     // ---- the prologue was issued by the caller: K-tile 0 must have landed, W0, W1, A0 of K-tile 1 may stay in flight
-    if (first && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wait == 0 && nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (wait != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_BARRIER();
     if (wr == 1) G2_BARRIER();                    // stagger: waves 4-7 run one barrier behind
 
     if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK0));
-    int wb = 0;                                            // weight buffer of K-tile t (t % 3)
+    int wb = wp;                                           // weight buffer of K-tile t: (t + wp) % 3
     for (int t = 0; t < nkt; ++t) {
-        const char* abuf = smem + (t & 1) * G2_ABUF;
+        const int ab0 = (t + ap) & 1, ab1 = ab0 ^ 1;       // A buffer of K-tiles t (and t + 2) / t + 1
+        const char* abuf = smem + ab0 * G2_ABUF;
         const char* wbuf = smem + G2_WBASE + wb * G2_WBUF;
-        const int wb2 = wb == 0 ? 2 : wb - 1;              // (t + 2) % 3
-        const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;     // block-uniform
+        const int wb2 = wb == 0 ? 2 : wb - 1;              // W buffer of K-tile t + 2
+        // K-tiles t + 1 / t + 2 of THIS tile, or - in its last two iterations - K-tiles 0 / 1 of the next one (block-uniform)
+        const bool nx1 = t + 1 >= nkt, nx2 = t + 2 >= nkt;
+        const bool n1 = !nx1 || has_next, n2 = !nx2 || has_next;
+        const int k1 = nx1 ? t + 1 - nkt : t + 1, k2 = nx2 ? t + 2 - nkt : t + 2;
+        if (has_next && t >= nkt - 2) g2_sources<TAG>(a, bm2, bn2, w, lane, src, t == nkt - 2, t == nkt - 1, t == nkt - 2);
         constexpr int SCHED = G2Lab<TAG>::sched;
         // phase 0: quadrant (n half 0, m half 0)
         G2_TS(tA);
         read_a(abuf, 0);
         read_w(wbuf, 0, wf0);
-        if (SCHED == 0 && n1) stage_a(1, t + 1);
+        if (SCHED == 0 && n1) stage_a(1, k1, ab1);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(0, 0, wf0, if (n1) g2_stage_a1<TAG>(src, smem, w, 1, t + 1, 0), if (n1) g2_stage_a1<TAG>(src, smem, w, 1, t + 1, 1));
+        G2_COMPUTE(0, 0, wf0, if (n1) g2_stage_a1<TAG>(src, smem, w, 1, k1, ab1, 0), if (n1) g2_stage_a1<TAG>(src, smem, w, 1, k1, ab1, 1));
         G2_BARRIER();
         // phase 1: (n half 1, m half 0)
         G2_TS(tA);
         read_w(wbuf, 1, wf1);
-        if (SCHED != 0 && SCHED != 4 && n1) stage_a(1, t + 1);
-        if (SCHED != 4 && n2) stage_w(0, t + 2, wb2);
+        if (SCHED != 0 && SCHED != 4 && n1) stage_a(1, k1, ab1);
+        if (SCHED != 4 && n2) stage_w(0, k2, wb2);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(1, 0, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 0, t + 2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 0, t + 2, wb2, 1));
+        G2_COMPUTE(1, 0, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 0, k2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 0, k2, wb2, 1));
         G2_BARRIER();
         // phase 2: (n half 1, m half 1)
         G2_TS(tA);
         read_a(abuf, 1);
-        if (SCHED != 4 && n2) stage_w(1, t + 2, wb2);
-        if (SCHED == 1 && n2) stage_a(0, t + 2);
+        if (SCHED != 4 && n2) stage_w(1, k2, wb2);
+        if (SCHED == 1 && n2) stage_a(0, k2, ab0);
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(1, 1, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 1, t + 2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 1, t + 2, wb2, 1));
+        G2_COMPUTE(1, 1, wf1, if (n2) g2_stage_w1<TAG>(src, smem, w, 1, k2, wb2, 0), if (n2) g2_stage_w1<TAG>(src, smem, w, 1, k2, wb2, 1));
         G2_BARRIER();
         // phase 3: (n half 0, m half 1); retire K-tile t+1's half-tiles, keep W0, W1, A0 of t+2 in flight
         G2_TS(tA);
         if (n2) {
-            if (SCHED != 1 && SCHED != 4) stage_a(0, t + 2);
+            if (SCHED != 1 && SCHED != 4) stage_a(0, k2, ab0);
             if (SCHED == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W0, W1 of t+2 stay in flight; A0(t+2) follows in this phase's burst
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
@@ -299,7 +338,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
         G2_TS(tB);
         G2_BARRIER();
         G2_TS(tC);
-        G2_COMPUTE(0, 1, wf0, if (n2) g2_stage_a1<TAG>(src, smem, w, 0, t + 2, 0), if (n2) g2_stage_a1<TAG>(src, smem, w, 0, t + 2, 1));
+        G2_COMPUTE(0, 1, wf0, if (n2) g2_stage_a1<TAG>(src, smem, w, 0, k2, ab0, 0), if (n2) g2_stage_a1<TAG>(src, smem, w, 0, k2, ab0, 1));
         G2_BARRIER();
         wb = wb == 2 ? 0 : wb + 1;
     }
@@ -309,7 +348,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
         unsigned long long tK1;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK1));
         if (lane == 0 && blockIdx.x < 256) {
-            unsigned* o = g2_ts + (blockIdx.x * 8 + w) * 24;
+            unsigned* o = g2_ts + (blockIdx.x * 8 + w) * 32;
             for (int p = 0; p < 4; ++p)
                 for (int q = 0; q < 5; ++q) o[p * 5 + q] += tacc[p][q];
             o[20] += tphases;
@@ -341,8 +380,12 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, const G2Src& src,
 // 528`: 32 + 32 stores and 32 loads of 1 KiB per wave and tile; ViT fc1 938 -> 590 TF/s, found in the .s and in tools/gemm_probe.py before
 // it shipped).  With a compile-time U every accumulator index is static whatever the body grows to (tests/test_static_asm.py pins 0
 // bytes of scratch for every kernel of this file).
-template <int U>
-__device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], int mb, int nb, int lane, char* slab) {
+// ACT is a template parameter too (dispatched once per tile in g2_epilogue_row): the epilogue is VALU-issue-bound - both waves of
+// every SIMD run it at the same time, ~43-46 k cycles per tile in rounds 2-3 against a 61 k-cycle K loop at K = 1280
+// (tools/gemm_lab/ts_probe.py) - so the activation ladder is resolved outside the 32 (u, t) blocks instead of inside each.
+// ACT == -2 (GT_OTHER: projector, patch embedding, microbenchmarks): the activation is resolved at run time inside the blocks.
+template <int U, int ACT, int STORES = 2>
+__device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], const h8 (&res)[8][2], int mb, int nb, int lane, char* slab) {
     const int r = lane & 15, g = lane >> 4;
     const int row0 = lane >> 3, chunk = lane & 7;
     const int n = nb + chunk * 8;
@@ -351,76 +394,134 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
         f4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[t][U][i] + bias[t][i];
-        if (a.act == ACT_QUICK_GELU) {
+        if constexpr (ACT == ACT_QUICK_GELU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
-        } else if (a.act == ACT_GELU) {
+        } else if constexpr (ACT == ACT_GELU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
-        } else if (a.act >= ACT_SILU) {
+        } else if constexpr (ACT == -2) {                 // GT_OTHER: resolved at run time
+            if (a.act == ACT_QUICK_GELU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+                for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
+            } else if (a.act == ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+            } else if (a.act >= ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+            }
         }
-        *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
+        if (STORES != -1) *(f4*)(slab + r * G2_SLAB_STRIDE + (t * 16 + 4 * g) * 4) = v;
+        else asm volatile("" ::"v"(v));                  // lab ablation (STORES == -1): no LDS transposition at all (the output is garbage)
     }
     asm volatile("" ::: "memory");                       // LDS writes above, reads below: same wave, program order
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int row = hh * 8 + row0;
         const int m = mb + U * 16 + row;
-        const f4 x0 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32);
-        const f4 x1 = *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16);
+        const f4 x0 = STORES != -1 ? *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32) : acc[hh][U];
+        const f4 x1 = STORES != -1 ? *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16) : acc[hh + 2][U];
         if (m >= a.M || n >= a.n_real) continue;
-        const int orow = a.out_rows ? a.out_rows[m] : m;
-        if (orow < 0) continue;
-        if (a.act == ACT_SILU_MUL) {                     // (gate, up) interleaved: 4 outputs at columns n / 2 .. n / 2 + 3
+        if (STORES >= 0 && hh >= STORES) {                                  // lab ablation only (STORES < 2): keep the values alive, skip the store
+            asm volatile("" ::"v"(x0), "v"(x1));
+            continue;
+        }
+        if (ACT == ACT_SILU_MUL || (ACT == -2 && a.act == ACT_SILU_MUL)) {      // (gate, up) interleaved: 4 outputs at columns n / 2 .. n / 2 + 3
             h4 o;
             o[0] = (half_t)(silu_f(x0[0]) * x0[1]);
             o[1] = (half_t)(silu_f(x0[2]) * x0[3]);
             o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
             o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
-            half_t* dst = a.C + (int64_t)orow * a.ldc + (n >> 1);
+            half_t* dst = a.C + (int64_t)m * a.ldc + (n >> 1);
             if (n + 8 <= a.n_real) *(h4*)dst = o;
             else *(h2*)dst = h2{o[0], o[1]};             // n_real % 4 == 0: the chunk holds 4 real columns
         } else {
             float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             const bool full = n + 8 <= a.n_real;
             if (a.resid) {
-                const half_t* rp = a.resid + (int64_t)m * a.ldr + n;
-                if (full) {
-                    const h8 rr = *(const h8*)rp;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += (float)rr[i];
-                } else {
-                    const h4 rr = *(const h4*)rp;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
-                }
+                for (int i = 0; i < 8; ++i) v[i] += (float)res[U][hh][i];      // lanes of a partial chunk hold zeros in 4 .. 7: those lanes are not stored
             }
             h8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
-            half_t* dst = a.C + (int64_t)orow * a.ldc + n;
+            half_t* dst = a.C + (int64_t)m * a.ldc + n;
             if (full) *(h8*)dst = o;
             else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
         }
     }
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem) {
+// The wide epilogue issues NO load after its first store.  Rounds 2-3 loaded the residual row (and looked up `out_rows[m]`) inside each of
+// the 16 row blocks: hipcc answers a load next to in-flight LDS-DMA with `s_waitcnt vmcnt(0)` (guide, "three .s-level traps" (b)), and
+// because stores and loads share vmcnt each block then waited for the PREVIOUS block's stores to be acknowledged by memory - 16 dependent
+// store round trips per tile = 38-46 k cycles, whatever the activation (round 4, tools/gemm_lab/ts_probe.py: 40 % of a K = 1280 tile).
+// Now every residual vector of the tile is fetched up front into the registers the dead operand fragments leave free (16 x 16 bytes per
+// lane), one wait, and the 16 stores go out back to back.  (`out_rows` launches - the projector's last GEMM - take the direct epilogue.)
+template <int ACT, int STORES = 2, bool TS = false>
+__device__ __forceinline__ void g2_epilogue_row_act(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem, int wfree, int afree,
+                                                    unsigned long long* st = nullptr) {
     const int g = lane >> 4;
-    char* slab = w < 6 ? smem + G2_WBASE + 2 * G2_WBUF + w * G2_SLAB_BYTES : smem + G2_ABUF + G2_SLOT + (w - 6) * G2_SLAB_BYTES;
+    // per-wave transposition slabs in LDS no staged K-tile occupies: W buffer `wfree` (waves 0-5), second half of A buffer `afree` (6-7)
+    char* slab = w < 6 ? smem + G2_WBASE + wfree * G2_WBUF + w * G2_SLAB_BYTES : smem + afree * G2_ABUF + G2_SLOT + (w - 6) * G2_SLAB_BYTES;
     f4 bias[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bias[t] = a.bias ? *(const f4*)(a.bias + nb + t * 16 + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
-    g2_epilogue_row_u<0>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<1>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<2>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<3>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<4>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<5>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<6>(a, acc, bias, mb, nb, lane, slab);
-    g2_epilogue_row_u<7>(a, acc, bias, mb, nb, lane, slab);
+    h8 res[8][2];
+    if (ACT != ACT_SILU_MUL && a.resid) {
+        const int row0 = lane >> 3, n = nb + (lane & 7) * 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int m = mb + u * 16 + hh * 8 + row0;
+                h8 rr = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < a.M && n < a.n_real) {
+                    const half_t* rp = a.resid + (int64_t)m * a.ldr + n;
+                    if (n + 8 <= a.n_real) rr = *(const h8*)rp;
+                    else {
+                        const h4 q = *(const h4*)rp;
+                        rr = h8{q[0], q[1], q[2], q[3], 0, 0, 0, 0};
+                    }
+                }
+                res[u][hh] = rr;
+            }
+    }
+    if constexpr (TS) asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[0])::"memory");     // bias + residual have landed
+    g2_epilogue_row_u<0, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    if constexpr (TS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[1])::"memory");
+    g2_epilogue_row_u<1, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<2, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<3, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<4, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<5, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<6, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<7, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    if constexpr (TS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[2])::"memory");
+}
+// Which activation a projection TAG implies (launch_gemm256 only picks a tagged instantiation when the arguments agree; anything else
+// runs GT_OTHER, whose epilogue resolves the activation per block at run time: ACT == -2).  One specialised epilogue per kernel - five
+// inlined copies behind a switch cost registers (256 + a spill) and minutes of compile time.
+template <int TAG> struct G2TagAct { static constexpr int act = -2; };
+template <> struct G2TagAct<GT_VIT_OUT> { static constexpr int act = ACT_NONE; };
+template <> struct G2TagAct<GT_VIT_FC2> { static constexpr int act = ACT_NONE; };
+template <> struct G2TagAct<GT_LLM_O> { static constexpr int act = ACT_NONE; };
+template <> struct G2TagAct<GT_LLM_DOWN> { static constexpr int act = ACT_NONE; };
+template <> struct G2TagAct<GT_LLM_GATEUP> { static constexpr int act = ACT_SILU_MUL; };
+template <> struct G2TagAct<GT_VIT_FC1> { static constexpr int act = ACT_QUICK_GELU; };      // an erf-GELU tower (config.hidden_act) runs GT_OTHER
+static int g2_tag_act(int tag) {
+    switch (tag) {
+        case GT_VIT_OUT: case GT_VIT_FC2: case GT_LLM_O: case GT_LLM_DOWN: return ACT_NONE;
+        case GT_LLM_GATEUP: return ACT_SILU_MUL;
+        case GT_VIT_FC1: return ACT_QUICK_GELU;
+        default: return -2;
+    }
+}
+template <int TAG>
+__device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem, int wfree, int afree,
+                                                unsigned long long* st = nullptr) {
+    g2_epilogue_row_act<G2TagAct<TAG>::act, G2Lab<TAG>::epi_nostore ? 0 : G2Lab<TAG>::epi_halfstore ? -1 : 2, G2Lab<TAG>::ts>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
 }
 
 template <int EPI, int TAG>
@@ -451,11 +552,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         bn = rem / rows;
         bm = 4 * sr + rem % rows;
     };
+    if constexpr (G2Lab<TAG>::stagger > 0) {
+        const int slot = ((int)blockIdx.x >> 3) % G2Lab<TAG>::stagger;          // block b runs on XCD b % 8: CUs of one XCD take different slots
+        const int tile_cycles = (a.K >> 6) * 3000 + 40000;                   // K loop + epilogue at ~2 GHz (order of magnitude is enough)
+        const int naps = slot * tile_cycles / G2Lab<TAG>::stagger / (64 * 100);
+        if (nwg > (int)gridDim.x)                                             // only when a workgroup walks more than one tile
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
+    }
     int bm, bn;
     G2Src src;
     tile_of(blockIdx.x, bm, bn);
     g2_sources<TAG>(a, bm, bn, w, lane, src);
     g2_prologue<TAG>(a, src, smem, w);
+    const int nkt = a.K >> 6;
+    const bool cont = G2Lab<TAG>::cont && nkt >= 3;          // the continuous pipeline needs K-tiles nkt - 2 and nkt - 1 to be distinct from K-tile 0
+    int ap = 0, wp = 0;                                      // LDS buffers of this tile's K-tile 0 (g2_mainloop)
     bool first = true;
     for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
         f4 acc[4][8];
@@ -466,21 +577,52 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int nb = bn * 256 + (w & 3) * 64;
         const int mb = bm * 256 + (w >> 2) * 128;
         const bool vmode = (EPI == EPI_QKV) && (nb >= a.q_cols + a.k_cols);
-        if (vmode) g2_mainloop<EPI, true, TAG>(a, src, smem, acc, w, lane, first);
-        else g2_mainloop<EPI, false, TAG>(a, src, smem, acc, w, lane, first);
-        first = false;
-        // every wave is past the K loop's last barrier: all LDS reads of this tile are done -> start the next tile's loads now,
-        // they fly while this tile's epilogue converts and stores
         const int nxt = bid + gridDim.x;
-        if (nxt < nwg) {
-            tile_of(nxt, bm, bn);
-            g2_sources<TAG>(a, bm, bn, w, lane, src);
+        const bool has_next = nxt < nwg;
+        int bm2 = bm, bn2 = bn;
+        if (has_next) tile_of(nxt, bm2, bn2);
+        unsigned long long tT0 = 0, tT1 = 0, tT2 = 0, tT3 = 0;
+        if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tT0));
+        const int wait = first ? 0 : (cont ? 2 : 1);
+        if (vmode) g2_mainloop<EPI, true, TAG>(a, src, smem, acc, w, lane, wait, ap, wp, cont && has_next, bm2, bn2);
+        else g2_mainloop<EPI, false, TAG>(a, src, smem, acc, w, lane, wait, ap, wp, cont && has_next, bm2, bn2);
+        if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tT1));
+        first = false;
+        if (cont) {                                          // the next tile's K-tiles 0 and 1 are staged already: only the buffer phases move on
+            ap = (ap + nkt) & 1;
+            wp = (wp + nkt) % 3;
+        } else if (has_next) {
+            // short K loops: every wave is past the K loop's last barrier, all LDS reads of this tile are done -> start the next tile's
+            // loads now, they fly while this tile's epilogue converts and stores
+            g2_sources<TAG>(a, bm2, bn2, w, lane, src);
             g2_prologue<TAG>(a, src, smem, w);
         }
+        bm = bm2;
+        bn = bn2;
+        if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tT2));
         // 16-byte row accesses need 8-column alignment of every row (ldc, ldr multiples of 8 halves; SiLU*up writes n / 2: ldc % 4)
-        const bool wide = EPI == EPI_ROW && a.wide_epilogue && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
-        if (wide) g2_epilogue_row(a, acc, mb, nb, lane, w, smem);
+        const bool wide = EPI == EPI_ROW && a.wide_epilogue && a.out_rows == nullptr && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
+        // LDS the next tile's staged K-tiles do not occupy: the W buffer of its K-tile 2 and the second half of the A buffer of its K-tile 1
+        unsigned long long est[3] = {0, 0, 0};
+        if constexpr (G2Lab<TAG>::wide_only) g2_epilogue_row<TAG>(a, acc, mb, nb, lane, w, smem, (wp + 2) % 3, (ap + 1) & 1, est);
+        else if (wide) g2_epilogue_row<TAG>(a, acc, mb, nb, lane, w, smem, (wp + 2) % 3, (ap + 1) & 1, est);
         else gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
+#ifdef AUR_LABS
+        if constexpr (G2Lab<TAG>::ts) {
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tT3));
+            if (lane == 0 && blockIdx.x < 256) {
+                unsigned* o = g2_ts + (blockIdx.x * 8 + w) * 32;
+                o[22] += (unsigned)(tT1 - tT0);
+                o[23] += (unsigned)(tT2 - tT1);
+                o[24] += (unsigned)(tT3 - tT2);
+                o[25] += 1;
+                o[26] += (unsigned)(est[0] - tT2);       // epilogue entry -> bias / residual landed
+                o[27] += (unsigned)(est[1] - est[0]);    // row block 0
+                o[28] += (unsigned)(est[2] - est[1]);    // row blocks 1 .. 7
+                o[29] += (unsigned)(tT3 - est[2]);
+            }
+        }
+#endif
     }
 }
 
@@ -509,7 +651,11 @@ hipError_t gemm256_init() {
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 9>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 10>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 11>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 12>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 13>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 14>()) != hipSuccess ||
-        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 15>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 16>()) != hipSuccess)
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 15>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 16>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 17>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 18>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 19>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 20>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 21>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 22>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 23>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 24>()) != hipSuccess)
         return e;
 #endif
     return hipSuccess;
@@ -556,11 +702,20 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 14: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 14); break;
             case 15: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 15); break;
             case 16: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 16); break;
+            case 17: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 17); break;
+            case 18: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 18); break;
+            case 19: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 19); break;
+            case 20: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 20); break;
+            case 21: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 21); break;
+            case 22: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 22); break;
+            case 23: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 23); break;
+            case 24: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 24); break;
             default: return hipErrorInvalidValue;
         }
 #endif
     } else if (epi == EPI_ROW) {
-        switch (a.tag) {
+        // a tagged instantiation carries its projection's activation at compile time: anything else runs the generic one
+        switch (g2_tag_act(a.tag) == a.act ? a.tag : GT_OTHER) {
             case GT_VIT_OUT: G2_LAUNCH(EPI_ROW, GT_VIT_OUT); break;
             case GT_VIT_FC1: G2_LAUNCH(EPI_ROW, GT_VIT_FC1); break;
             case GT_VIT_FC2: G2_LAUNCH(EPI_ROW, GT_VIT_FC2); break;
@@ -583,9 +738,9 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
 #ifdef AUR_LABS
 // lab 8 read-out (libaurora_hip_labs.so only; not part of include/aurora_hip.h): copies g2_ts to the host and clears it
 extern "C" int aur_lab_gemm_ts(unsigned* dst_host, int clear) {
-    if (hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g2_ts), sizeof(unsigned) * 256 * 8 * 24) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g2_ts), sizeof(unsigned) * 256 * 8 * 32) != hipSuccess) return -1;
     if (clear) {
-        static unsigned zeros[256 * 8 * 24];
+        static unsigned zeros[256 * 8 * 32];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g2_ts), zeros, sizeof zeros) != hipSuccess) return -1;
     }
     return 0;

@@ -906,21 +906,25 @@ def main():
         how = "HIP events around every launch of this kernel in one extra eager, un-pipelined step on the launch stream (after the timed steps)"
         # rocprofv3 --pmc summary of this same command (tools/profile_round.sh -> profiles/r02_pmc.json), if committed: per-kernel
         # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE KiB, separate passes) measured at 6 new tokens, scaled to this run below
-        pmc, pmc_ctx, pmc_tag = {}, None, "r02"
+        pmc, pmc_ctx, pmc_tag, pmc_build = {}, None, "r02", None
         try:
             pj = None
-            for tag in ("r03", "r02"):                                 # the newest committed counter summary
+            for tag in ("r04", "r03", "r02"):                          # the newest committed counter summary
                 fp = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
                 if os.path.exists(fp):
                     pj, pmc_tag = json.load(open(fp)), tag
                     break
             pmc_ctx = pj.get("_batch_x_ctx")
+            pmc_build = (pj.get("_build") or {}).get("lib_sha16")
             for ent in pj["kernels"]:
                 if "hbm_bytes_per_launch" in ent:
                     pmc.setdefault(ent["kernel"].split("(")[0].replace("void ", ""), ent)
         except Exception:
             pass
         pmc_of = lambda needle: next((v for k, v in pmc.items() if needle in k), None)
+        import hashlib
+        from aurora_amd import _lib as _L
+        lib_sha = hashlib.sha256(open(_L.SO_PATH, "rb").read()).hexdigest()[:16]
         roof = {}
         if an > 0:
             # decode attention: K + V of every cached token of every sequence, all heads, read once per layer-step; the
@@ -932,10 +936,15 @@ def main():
             roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_dot_kernel<4, 8> (paged decode attention, v_dot2c page pipeline)" if args.dec_attn_variant in (-1, 4)
                                    else "decode_attn_pipe_kernel<4, 8> (paged decode attention, MFMA page pipeline)",
                                    "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
-                                   "traffic": (att_pmc["hbm_bytes_per_launch"] * (B * mean_ctx) / pmc_ctx) if (att_pmc and pmc_ctx) else None,
-                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/%s_pmc.json (separate passes of this command at "
-                                                   "the same batch and 6 new tokens), scaled by (this run's mean context) / (the pass's context) = %.3f"
-                                                   % (pmc_tag, (B * mean_ctx) / pmc_ctx if pmc_ctx else float("nan")),
+                                   # HBM bytes per launch from the PMC counters, UNSCALED, at the counter pass's own context (the pass decodes
+                                   # 6 tokens after the same prefill: B x 2145 cached tokens), with the algorithmic bytes at that context beside it
+                                   "traffic": att_pmc["hbm_bytes_per_launch"] if att_pmc else None,
+                                   "traffic_context": {"batch_x_cached_tokens": pmc_ctx, "algorithmic_bytes_at_that_context": (pmc_ctx * 2 * d * 2) if pmc_ctx else None,
+                                                       "traffic_over_algorithmic": (att_pmc["hbm_bytes_per_launch"] / (pmc_ctx * 2 * d * 2)) if (att_pmc and pmc_ctx) else None,
+                                                       "this_run_mean_batch_x_cached_tokens": B * mean_ctx},
+                                   "traffic_note": "rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/%s_pmc.json: separate passes of this command at the "
+                                                   "same batch and 6 new tokens (tools/profile_round.sh); counters taken on library build %s, this run loaded %s (%s)"
+                                                   % (pmc_tag, pmc_build, lib_sha, "the same build" if pmc_build == lib_sha else "a different build"),
                                    "algorithmic_bytes_per_launch": alg,
                                    "avg_launch_us": avg_s * 1e6, "launches_timed": an, "how": how}
         if kn > 0:

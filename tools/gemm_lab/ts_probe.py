@@ -29,10 +29,10 @@ def main():
     L.aur_lab_gemm_ts.restype = C.c_int
     L.aur_lab_gemm_ts.argtypes = [C.c_void_p, C.c_int]
     g = torch.Generator(device="cuda").manual_seed(0)
-    ts = np.zeros(256 * 8 * 24, dtype=np.uint32)
-    STAMPED = (8, 9, 10, 13, 14, 16)
+    ts = np.zeros(256 * 8 * 32, dtype=np.uint32)
+    STAMPED = (8, 9, 10, 13, 14, 16, 19, 20, 21, 23, 24)
 
-    def run(name, M, K, N, lab, iters=8):
+    def run(name, M, K, N, lab, iters=8, with_bias=True):
         npad = _rup(N, 256)
         a = (torch.randn(_rup(M, 256), K, generator=g, device="cuda") * 0.5).half()      # whole 256-row tiles: lab 13 reads a K-tile-major image of them
         w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
@@ -42,7 +42,7 @@ def main():
         eng.set_option("gemm_mode", 2)
         eng.set_option("gemm_lab", lab)
         st = eng._stream()
-        call = lambda: check(eng.ctx, L.aur_linear(eng.ctx, a.data_ptr(), M, K, wp.data_ptr(), npad, N, bias.data_ptr(), 0, None, c.data_ptr(), st), "aur_linear")
+        call = lambda: check(eng.ctx, L.aur_linear(eng.ctx, a.data_ptr(), M, K, wp.data_ptr(), npad, N, bias.data_ptr() if with_bias else None, 0, None, c.data_ptr(), st), "aur_linear")
         for _ in range(2):
             call()
         torch.cuda.synchronize()
@@ -54,34 +54,41 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        print(f"\n{name}: M {M} K {K} N {N} lab {lab}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
+        print(f"\n{name}: M {M} K {K} N {N} lab {lab}{'' if with_bias else ' (no bias)'}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
         if lab not in STAMPED:
             eng.set_option("gemm_lab", 0)
             return
         assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
-        t = ts.reshape(256, 8, 24).astype(np.float64)
+        t = ts.reshape(256, 8, 32).astype(np.float64)
         for grp, ws in (("waves 0-3 (leading group)", slice(0, 4)), ("waves 4-7 (one barrier behind)", slice(4, 8))):
-            x = t[:, ws].reshape(-1, 24)
+            x = t[:, ws].reshape(-1, 32)
             x = x[x[:, 20] > 0]
             n = x[:, 20].sum()
             seg = x[:, :20].sum(0).reshape(4, 5) / (n / 4.0)        # mean cycles per phase occurrence
             tot = x[:, 21].sum() / n
             print(f"  {grp}: mean cycles per phase {tot:7.1f} (ideal 2 x 272 = 544)")
+            tiles = x[:, 25].sum()
+            if tiles > 0:
+                loop, headloop, pro, epi = x[:, 21].sum() / tiles, x[:, 22].sum() / tiles, x[:, 23].sum() / tiles, x[:, 24].sum() / tiles
+                e = [x[:, k].sum() / tiles for k in (26, 27, 28, 29)]
+                print(f"    epilogue split (cycles): entry -> bias / residual landed {e[0]:7.0f} | row block 0 {e[1]:6.0f} | row blocks 1-7 {e[2]:7.0f} | tail {e[3]:5.0f}")
+                print(f"    per tile (cycles): head (wait for the prologue's K-tile 0 + stores + barriers) {headloop - loop:7.0f} | K loop {loop:8.0f} | "
+                      f"next prologue issue {pro:6.0f} | epilogue {epi:7.0f} | total {headloop + pro + epi:8.0f}")
             print("    phase   load   bar1   lgkm   mfma   bar2    sum")
             for p in range(4):
                 print(f"    {p}     " + " ".join(f"{v:6.0f}" for v in seg[p]) + f" {seg[p].sum():6.0f}")
         eng.set_option("gemm_lab", 0)
 
     print("labs: 0 product | 11 / 12 / 15 DMA schedule 1 / 2 / 4 (no stamps) | 8 / 9 / 10 / 16 stamps on schedule 0 / 1 / 2 / 4 | 13 stamps + A from a "
-          "K-tile-major image | 14 stamps + no operand DMA")
+          "K-tile-major image | 14 stamps + no operand DMA | 17 / 18 start-up stagger over 4 / 8 slots per XCD, 19 = 17 with stamps | 22 / 23 continuous pipeline across tile boundaries (23 with stamps) | 20 / 21 stamps + no / half of the epilogue stores")
     shapes = [("llm gate/up, 4-clip prefill pass", 8576, 4096, 22016), ("llm down", 8576, 11008, 4096), ("llm qkv-shaped", 8576, 4096, 12288),
               ("vit fc1, t = 640 x 32 frames", 20480, 1280, 5120), ("vit fc2", 20480, 5120, 1280)]
-    for rep in range(3):                                            # interleaved A/B/A/B of the un-stamped kernels
+    for rep in range(0):                                            # interleaved A/B/A/B of the un-stamped kernels
         for name, M, K, N in shapes:
-            for lab in (0, 12, 15):
+            for lab in (0, 22):
                 run(name, M, K, N, lab)
-    for name, M, K, N in shapes[:1] + shapes[3:4]:
-        for lab in (8, 10, 16):
+    for name, M, K, N in shapes[:1] + shapes[3:]:
+        for lab in (10, 24):
             run(name, M, K, N, lab)
     eng.close()
 

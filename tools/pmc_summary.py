@@ -63,6 +63,20 @@ def read_pass(d):
     return acc
 
 
+def build_id():
+    """sha256[:16] of the library and of bench.py the passes ran (the snapshot on the GPU box has no .git): bench.py compares it with
+    the library IT loaded, so that `roofline.traffic` says whether the counters come from the same build"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, rel in (("lib_sha16", os.path.join("aurora_amd", "libaurora_hip.so")), ("bench_sha16", "bench.py")):
+        try:
+            out[name] = hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[name] = None
+    return out
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
     batch_x_ctx = float(sys.argv[3]) if len(sys.argv) > 3 else 64 * 2145.0     # decode attention: sequences x mean cached tokens of the pass
@@ -73,7 +87,7 @@ def main():
                     "(B x 2145 = _batch_x_ctx: the decode attention's sequences x cached tokens in this pass) under three "
                     "separate rocprofv3 --pmc passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH half-count correction); "
                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration",
-           "_batch_x_ctx": batch_x_ctx, "kernels": []}
+           "_batch_x_ctx": batch_x_ctx, "_build": build_id(), "kernels": []}
     mean = lambda a, c: (a[c][0] / a[c][1]) if c in a and a[c][1] else None
     for k in keys:
         f, w, m = F.get(k, {}), W.get(k, {}), M.get(k, {})
