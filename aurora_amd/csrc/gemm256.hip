@@ -80,6 +80,7 @@ template <int TAG> struct G2Lab {
 // lab 8: per workgroup and wave, cycles summed over the K loops of all its tiles, [phase 0..3][load segment, barrier 1, lgkmcnt wait,
 // MFMA burst, barrier 2], then [20] = phases timed, [21] = total cycles of the K loops.  Stamps are s_memtime (SMEM: counted by lgkmcnt)
 // issued WITHOUT a wait of their own: they are collected behind the schedule's existing s_waitcnt lgkmcnt(0).
+__device__ unsigned g2_ts2[256 * 8 * 4];
 __device__ unsigned g2_ts[256 * 8 * 32];     // + [22] tile head + K loop, [23] next tile's prologue issue, [24] epilogue, [25] tiles (cycles per wave)
 #endif
 template <int AUX>
@@ -384,8 +385,13 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, G2Src& src, char*
 // every SIMD run it at the same time, ~43-46 k cycles per tile in rounds 2-3 against a 61 k-cycle K loop at K = 1280
 // (tools/gemm_lab/ts_probe.py) - so the activation ladder is resolved outside the 32 (u, t) blocks instead of inside each.
 // ACT == -2 (GT_OTHER: projector, patch embedding, microbenchmarks): the activation is resolved at run time inside the blocks.
+#define G2_EST(i)                                                                                     \
+    do {                                                                                              \
+        if (U == 0 && fine) asm volatile("s_memtime %0" : "=s"(fine[i])::"memory");                   \
+    } while (0)
 template <int U, int ACT, int STORES = 2>
-__device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], const h8 (&res)[8][2], int mb, int nb, int lane, char* slab) {
+__device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], const h8 (&res)[8][2], int mb, int nb, int lane, char* slab,
+                                                  unsigned long long* fine = nullptr) {        // lab: 5 stamps inside row block 0
     const int r = lane & 15, g = lane >> 4;
     const int row0 = lane >> 3, chunk = lane & 7;
     const int n = nb + chunk * 8;
@@ -416,12 +422,17 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
         else asm volatile("" ::"v"(v));                  // lab ablation (STORES == -1): no LDS transposition at all (the output is garbage)
     }
     asm volatile("" ::: "memory");                       // LDS writes above, reads below: same wave, program order
+    G2_EST(0);                                           // the 4 ds_write_b128 are issued
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int row = hh * 8 + row0;
         const int m = mb + U * 16 + row;
         const f4 x0 = STORES != -1 ? *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32) : acc[hh][U];
         const f4 x1 = STORES != -1 ? *(const f4*)(slab + row * G2_SLAB_STRIDE + chunk * 32 + 16) : acc[hh + 2][U];
+        if (U == 0 && fine) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (hh == 0) G2_EST(1); else G2_EST(3);      // this half's two ds_read_b128 have returned
+        }
         if (m >= a.M || n >= a.n_real) continue;
         if (STORES >= 0 && hh >= STORES) {                                  // lab ablation only (STORES < 2): keep the values alive, skip the store
             asm volatile("" ::"v"(x0), "v"(x1));
@@ -450,9 +461,11 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
             if (full) *(h8*)dst = o;
             else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
         }
+        if (hh == 0) G2_EST(2); else G2_EST(4);          // this half's store is issued
     }
     asm volatile("" ::: "memory");
 }
+#undef G2_EST
 // The wide epilogue issues NO load after its first store.  Rounds 2-3 loaded the residual row (and looked up `out_rows[m]`) inside each of
 // the 16 row blocks: hipcc answers a load next to in-flight LDS-DMA with `s_waitcnt vmcnt(0)` (guide, "three .s-level traps" (b)), and
 // because stores and loads share vmcnt each block then waited for the PREVIOUS block's stores to be acknowledged by memory - 16 dependent
@@ -489,7 +502,7 @@ __device__ __forceinline__ void g2_epilogue_row_act(const GemmArgs& a, f4 (&acc)
             }
     }
     if constexpr (TS) asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[0])::"memory");     // bias + residual have landed
-    g2_epilogue_row_u<0, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<0, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab, TS ? st + 3 : nullptr);
     if constexpr (TS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[1])::"memory");
     g2_epilogue_row_u<1, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
     g2_epilogue_row_u<2, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         // 16-byte row accesses need 8-column alignment of every row (ldc, ldr multiples of 8 halves; SiLU*up writes n / 2: ldc % 4)
         const bool wide = EPI == EPI_ROW && a.wide_epilogue && a.out_rows == nullptr && (a.act == ACT_SILU_MUL ? (a.ldc & 3) == 0 : ((a.ldc | (a.resid ? a.ldr : 0)) & 7) == 0);
         // LDS the next tile's staged K-tiles do not occupy: the W buffer of its K-tile 2 and the second half of the A buffer of its K-tile 1
-        unsigned long long est[3] = {0, 0, 0};
+        unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (G2Lab<TAG>::wide_only) g2_epilogue_row<TAG>(a, acc, mb, nb, lane, w, smem, (wp + 2) % 3, (ap + 1) & 1, est);
         else if (wide) g2_epilogue_row<TAG>(a, acc, mb, nb, lane, w, smem, (wp + 2) % 3, (ap + 1) & 1, est);
         else gemm_epilogue<EPI, 4, 8>(a, acc, mb, nb, lane, vmode);
@@ -620,6 +633,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 o[27] += (unsigned)(est[1] - est[0]);    // row block 0
                 o[28] += (unsigned)(est[2] - est[1]);    // row blocks 1 .. 7
                 o[29] += (unsigned)(tT3 - est[2]);
+                o[30] += (unsigned)(est[3] - est[0]);    // row block 0: bias adds + 4 ds_write_b128 issued
+                o[31] += (unsigned)(est[4] - est[3]);    //              first half's reads back
+                g2_ts2[(blockIdx.x * 8 + w) * 4 + 0] += (unsigned)(est[5] - est[4]);    // first half converted + stored
+                g2_ts2[(blockIdx.x * 8 + w) * 4 + 1] += (unsigned)(est[6] - est[5]);    // second half's reads back
+                g2_ts2[(blockIdx.x * 8 + w) * 4 + 2] += (unsigned)(est[7] - est[6]);    // second half stored
             }
         }
 #endif
@@ -737,6 +755,14 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
 
 #ifdef AUR_LABS
 // lab 8 read-out (libaurora_hip_labs.so only; not part of include/aurora_hip.h): copies g2_ts to the host and clears it
+extern "C" int aur_lab_gemm_ts2(unsigned* dst_host, int clear) {
+    if (hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g2_ts2), sizeof(unsigned) * 256 * 8 * 4) != hipSuccess) return -1;
+    if (clear) {
+        static unsigned zeros[256 * 8 * 4];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g2_ts2), zeros, sizeof zeros) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int aur_lab_gemm_ts(unsigned* dst_host, int clear) {
     if (hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g2_ts), sizeof(unsigned) * 256 * 8 * 32) != hipSuccess) return -1;
     if (clear) {

@@ -167,7 +167,12 @@ def test_eight_rank_dry_run_of_the_configs3_command():
     env["AURORA_DIST_BACKEND"] = "gloo"
     common = ["--config", "cfg4", "--tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-power"]
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + common, cwd=ROOT, capture_output=True, text=True, timeout=1800, env=env)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    if r.returncode != 0:                                                  # keep the whole log: a rank's traceback sits far above torchrun's summary
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "eight_rank_dry_run.err"), "w") as f:
+            f.write(r.stdout + "\n==== stderr\n" + r.stderr)
+    tb = [ln for ln in r.stderr.splitlines() if "Error" in ln or "error" in ln or "Traceback" in ln or "assert" in ln][:12]
+    assert r.returncode == 0, (tb, r.stderr[-1500:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 8 and d["dist_backend"] == "gloo" and d["config"]["preset"] == "cfg4" and d["config"]["clips_per_gpu_per_step"] == 8
     assert d["config"]["frames"] == 8 and d["config"]["max_new_tokens"] == 256 and d["config"]["token_kept_ratio"] == 0.3

@@ -30,6 +30,9 @@ def main():
     L.aur_lab_gemm_ts.argtypes = [C.c_void_p, C.c_int]
     g = torch.Generator(device="cuda").manual_seed(0)
     ts = np.zeros(256 * 8 * 32, dtype=np.uint32)
+    ts2 = np.zeros(256 * 8 * 4, dtype=np.uint32)
+    L.aur_lab_gemm_ts2.restype = C.c_int
+    L.aur_lab_gemm_ts2.argtypes = [C.c_void_p, C.c_int]
     STAMPED = (8, 9, 10, 13, 14, 16, 19, 20, 21, 23, 24)
 
     def run(name, M, K, N, lab, iters=8, with_bias=True):
@@ -46,7 +49,7 @@ def main():
         for _ in range(2):
             call()
         torch.cuda.synchronize()
-        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
+        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0 and L.aur_lab_gemm_ts2(ts2.ctypes.data, 1) == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
@@ -58,8 +61,14 @@ def main():
         if lab not in STAMPED:
             eng.set_option("gemm_lab", 0)
             return
-        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0
+        assert L.aur_lab_gemm_ts(ts.ctypes.data, 1) == 0 and L.aur_lab_gemm_ts2(ts2.ctypes.data, 1) == 0
         t = ts.reshape(256, 8, 32).astype(np.float64)
+        t2 = ts2.reshape(256, 8, 4).astype(np.float64)
+        tl = t[:, :, 25].sum()
+        if tl > 0:
+            f = [t[:, :, 30].sum() / tl, t[:, :, 31].sum() / tl] + [t2[:, :, k].sum() / tl for k in range(3)]
+            print(f"    row block 0 in detail (cycles): bias adds + 4 ds_write issued {f[0]:6.0f} | 1st half's 2 ds_read back {f[1]:6.0f} | converted + stored {f[2]:6.0f} | "
+                  f"2nd half's reads back {f[3]:6.0f} | stored {f[4]:6.0f}")
         for grp, ws in (("waves 0-3 (leading group)", slice(0, 4)), ("waves 4-7 (one barrier behind)", slice(4, 8))):
             x = t[:, ws].reshape(-1, 32)
             x = x[x[:, 20] > 0]
@@ -88,7 +97,7 @@ def main():
             for lab in (0, 22):
                 run(name, M, K, N, lab)
     for name, M, K, N in shapes[:1] + shapes[3:]:
-        for lab in (10, 24):
+        for lab in (10,):
             run(name, M, K, N, lab)
     eng.close()
 
