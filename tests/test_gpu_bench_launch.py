@@ -166,7 +166,10 @@ def test_eight_rank_dry_run_of_the_configs3_command():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["AURORA_DIST_BACKEND"] = "gloo"
     common = ["--config", "cfg4", "--tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-power"]
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + common, cwd=ROOT, capture_output=True, text=True, timeout=1800, env=env)
+    for attempt in range(2):             # one retry: 8 fresh processes + a rendezvous right behind the previous tests' torchrun jobs flaked once in 5 runs
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + common, cwd=ROOT, capture_output=True, text=True, timeout=1800, env=env)
+        if r.returncode == 0:
+            break
     if r.returncode != 0:                                                  # keep the whole log: a rank's traceback sits far above torchrun's summary
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "eight_rank_dry_run.err"), "w") as f:
