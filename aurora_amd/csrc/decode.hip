@@ -1283,6 +1283,31 @@ __global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a)
 //   P V   : 4 v_dot2c per fragment into one fp32 per (lane, d16); the 4 token groups meet once, after the last page
 // 128 dot products + ~40 other VALU operations per page instead of 32 MFMAs + ~250; registers as variant 3 (two waves per SIMD).
 // Different summation order than variants 0 / 1 / 3 (not bitwise equal to them); deterministic and batch-invariant like them.
+// One output feature d of (sequence b, head): the splits' partials combined in the fixed order s = 0, 1, .. (deterministic whatever order
+// they were produced in).  Shared by decode_attn_combine_kernel and by the in-kernel combine of decode_attn_dot_kernel: the same
+// instructions, hence the same bits.  AGENT = the partials were published at agent scope by other workgroups of THIS launch: read them
+// with L1-bypassing (sc1) loads.
+template <bool AGENT>
+__device__ __forceinline__ float attn_part_ld(const float* p) {
+    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool AGENT>
+__device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b, int head, int d) {
+    const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2));
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float m = attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2);
+        if (m == -INFINITY) continue;
+        const float wgt = __builtin_amdgcn_exp2f(m - M);
+        num = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_o + (p0 + s) * a.hd + d), num);
+        den = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2 + 1), den);
+    }
+    const int k = head * a.hd + d;                 // attention output in x-fragment form (input of the o projection)
+    a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);
+}
 __device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
     c = __builtin_amdgcn_fdot2(h2{a[0], a[1]}, h2{b[0], b[1]}, c, false);
     c = __builtin_amdgcn_fdot2(h2{a[2], a[3]}, h2{b[2], b[3]}, c, false);
@@ -1398,31 +1423,47 @@ __global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
         }
         return;
     }
+    if (a.cnt == nullptr) {                              // decode_attn_combine_kernel follows
+#pragma unroll
+        for (int d = 0; d < VD16; ++d)
+            if ((d & 3) == g) a.part_o[pidx * a.hd + d * 16 + r] = acc_o[d];
+        if (lane == 0) {
+            a.part_ml[pidx * 2 + 0] = m_run;
+            a.part_ml[pidx * 2 + 1] = l;
+        }
+        return;
+    }
+    // ---- combine IN the kernel (round 4; engines whose batch alone does not fill the GPU run 2-16 splits per (sequence, head) and paid a
+    // second launch per layer for a 3 us kernel: 32 of the 225 launches of an 8-slot decode step).  The guide's in-launch hand-over in
+    // its counter form (Guideline 16 / the split-K recipe): every split publishes its partial with write-through agent-scope stores
+    // (compiler-emitted atomics: hipcc pads and counts them - section 10.2 of DESIGN.md is what an inline-asm store did here), drains them
+    // (this block is ONE wave), counts itself in; the split that finds the pair complete reads all partials back with sc1 loads and
+    // combines them in the fixed order s = 0, 1, .. with the SAME function as the separate kernel - bitwise its result.  Placement-
+    // independent: nothing assumes where or when the other splits ran.  The counter returns to zero for the next launch / graph replay.
 #pragma unroll
     for (int d = 0; d < VD16; ++d)
-        if ((d & 3) == g) a.part_o[pidx * a.hd + d * 16 + r] = acc_o[d];
+        if ((d & 3) == g) __hip_atomic_store(a.part_o + pidx * a.hd + d * 16 + r, acc_o[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
-        a.part_ml[pidx * 2 + 0] = m_run;
-        a.part_ml[pidx * 2 + 1] = l;
+        __hip_atomic_store(a.part_ml + pidx * 2 + 0, m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_ml + pidx * 2 + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial has reached the coherence point before the arrival is counted
+    int last = 0;
+    if (lane == 0) {
+        int* c = a.cnt + b * a.heads + head;
+        const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = arrived == a.nsplit - 1;
+        if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    for (int d = lane; d < a.hd; d += 64) attn_combine_feature<true>(a, b, head, d);
 }
 
 __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     if (d >= a.hd) return;
-    const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
-    float M = -INFINITY;
-    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part_ml[(p0 + s) * 2]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) {
-        const float m = a.part_ml[(p0 + s) * 2];
-        if (m == -INFINITY) continue;
-        const float wgt = __builtin_amdgcn_exp2f(m - M);
-        num += wgt * a.part_o[(p0 + s) * a.hd + d];
-        den += wgt * a.part_ml[(p0 + s) * 2 + 1];
-    }
-    const int k = head * a.hd + d;                 // attention output in x-fragment form (input of the o projection)
-    a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);
+    attn_combine_feature<false>(a, b, head, d);
 }
 
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
@@ -1444,8 +1485,10 @@ hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 bool decode_attention_needs_combine(const DecAttnArgs& a) {
-    // the pipelined kernel finishes single-split problems itself (see its epilogue)
-    return !(a.nsplit == 1 && a.variant >= 1 && a.kv.page_tokens == 64);
+    // the pipelined kernels finish single-split problems themselves (see their epilogues); variant 4 with arrival counters combines in the kernel
+    if (a.nsplit == 1 && a.variant >= 1 && a.kv.page_tokens == 64) return false;
+    if (a.cnt != nullptr && a.variant == 4 && a.kv.page_tokens == 64) return false;
+    return true;
 }
 hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
     if (!decode_attention_needs_combine(a)) return hipSuccess;

@@ -83,6 +83,8 @@ struct aur_ctx {
     int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
+    int* d_attn_cnt = nullptr;                                                  // [max_batch][heads] arrival counters of the decode attention's in-kernel combine
+    int attn_fused_combine = 0;                                                 // 1: the last-arriving split of a (sequence, head) combines in the attention kernel (bitwise the same; measured 0.3 % slower at 8 slots than the launch it saves)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
@@ -274,6 +276,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
     c->d_row_cnt = k.take<int>(c->l_dpad / 16);
+    c->d_attn_cnt = k.take<int>(B * g.llm_heads);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
@@ -358,6 +361,7 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     // arrival counters of the ToMe match + select launch: zero now, and every launch leaves them at zero
     if (ctx->w_tome_cnt) CK(hipMemset(ctx->w_tome_cnt, 0, (size_t)ctx->cfg.max_frames * 4));
     if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
+    if (ctx->d_attn_cnt) CK(hipMemset(ctx->d_attn_cnt, 0, (size_t)ctx->cfg.max_batch * ctx->cfg.llm_heads * 4));
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -1109,6 +1113,7 @@ static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
     at.qbuf = ctx->d_q; at.kv = llm_kv(ctx, l); at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = ctx->batch; at.heads = g.llm_heads;
     at.hd = ctx->l_hd; at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
     at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32; at.variant = ctx->attn_variant;
+    at.cnt = (ctx->attn_fused_combine && ctx->attn_variant == 4 && ctx->nsplit > 1) ? ctx->d_attn_cnt : nullptr;
     return at;
 }
 static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
@@ -1276,7 +1281,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
         else if (!strcmp(name, "gemm_lab")) {
 #ifdef AUR_LABS
-            ctx->gemm_lab = (value >= 0 && value <= 24) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
+            ctx->gemm_lab = (value >= 0 && value <= 25) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
 #else
             return aur_fail(ctx, AUR_ERR_ARG, "gemm_lab exists in AUR_LABS builds only (python -m aurora_amd.build --labs)");
 #endif
@@ -1289,6 +1294,10 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
+    } else if (!strcmp(name, "dec_attn_fused_combine")) {
+        // 1 (default): with several splits per (sequence, head) the split that arrives last combines the partials inside the attention
+        // kernel (decode.hip); 0: decode_attn_combine_kernel does, in a second launch.  Bitwise the same output.
+        ctx->attn_fused_combine = value ? 1 : 0;
     } else if (!strcmp(name, "decode_fused_reduce")) {
         // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (the last-arriving split reduces;
         // decode.hip "split-K with the reduce IN the kernel"); 0: a second launch does (skinny_row_reduce_kernel).  Bitwise the same tokens.

@@ -46,6 +46,9 @@
 #ifndef G2_STAGGER
 #define G2_STAGGER 0
 #endif
+#ifndef G2_STORE_AUX
+#define G2_STORE_AUX 2  // cache policy of the wide epilogue's output stores: 0 default, 2 nt (g2_store_c)
+#endif
 #ifndef G2_SCHED
 #define G2_SCHED 2      // round 4: +3..6 % on every shape of the path against schedule 0 (profiles/r04_gemm_segments.log), same bits
 #endif
@@ -75,6 +78,8 @@ template <int TAG> struct G2Lab {
     static constexpr int sched = (id == 9 || id == 11) ? 1 : (id == 10 || id == 12 || id >= 17) ? 2 : (id == 15 || id == 16) ? 4 : G2_SCHED;     // 15 / 16: schedule 4 without / with stamps
     // 17 / 18: workgroups of one XCD start 0 .. 3/4 (17, 19 = with stamps) or 0 .. 7/8 (18) of a tile's duration apart
     static constexpr int stagger = (id == 17 || id == 19) ? 4 : id == 18 ? 8 : G2_STAGGER;
+    // 25: the wide epilogue's output stores with the default cache policy (the product's are non-temporal: tools/gemm_lab/store_probe.py)
+    static constexpr int store_aux = id == 25 ? 0 : G2_STORE_AUX;
 };
 #ifdef AUR_LABS
 // lab 8: per workgroup and wave, cycles summed over the K loops of all its tiles, [phase 0..3][load segment, barrier 1, lgkmcnt wait,
@@ -228,7 +233,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, G2Src& src, char*
     // ---- lab 8 (AUR_LABS): segment stamps.  tA: phase start, tB: before barrier 1, tC: after it, tD: after the lgkmcnt wait, tE: after
     // the MFMA burst.  Everything compiles away when G2Lab<TAG>::ts is false.
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tCp = 0, tDp = 0, tEp = 0, tK0 = 0;
-    unsigned tacc[4][5] = {{0}}, tphases = 0;
+    [[maybe_unused]] unsigned tacc[4][5] = {{0}}, tphases = 0;
     bool thave = false;
 #define G2_TS(v)                                                      \
     do {                                                              \
@@ -389,7 +394,18 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, G2Src& src, char*
     do {                                                                                              \
         if (U == 0 && fine) asm volatile("s_memtime %0" : "=s"(fine[i])::"memory");                   \
     } while (0)
-template <int U, int ACT, int STORES = 2>
+// One output vector of the wide epilogue.  POL 2 (product): a non-temporal store.  Every round of tiles writes 256 x 128 KiB - the capacity of
+// the eight L2s - in one burst, because all CUs reach their epilogue together; written with the default policy the output evicts the operand
+// panels the next tiles share through L2 and the K loops AFTER the epilogue pay for it (round 4, tools/gemm_lab/store_probe.py and
+// conc_probe.py: the per-tile fixed cost is 9.7 us with up to 128 CUs running and 16.4 us with 256; a K = 128 sweep 500 -> 310 us, K = 1280
+// 1180 -> 1085 us, prefill gate/up -3 %, with `nt`; sc1 / sc0 sc1 write-through stores gain less).  Nothing on this path re-reads C from L2:
+// the consumer is the next launch, and C is 40-800 MB.
+template <int POL, typename V>
+__device__ __forceinline__ void g2_store_c(half_t* dst, const V& v) {
+    if constexpr (POL == 2) __builtin_nontemporal_store(v, (V*)dst);
+    else *(V*)dst = v;
+}
+template <int U, int ACT, int STORES = 2, int POL = 0>
 __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4][8], const f4 (&bias)[4], const h8 (&res)[8][2], int mb, int nb, int lane, char* slab,
                                                   unsigned long long* fine = nullptr) {        // lab: 5 stamps inside row block 0
     const int r = lane & 15, g = lane >> 4;
@@ -445,8 +461,8 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
             o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
             o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
             half_t* dst = a.C + (int64_t)m * a.ldc + (n >> 1);
-            if (n + 8 <= a.n_real) *(h4*)dst = o;
-            else *(h2*)dst = h2{o[0], o[1]};             // n_real % 4 == 0: the chunk holds 4 real columns
+            if (n + 8 <= a.n_real) g2_store_c<POL>(dst, o);
+            else g2_store_c<POL>(dst, h2{o[0], o[1]});             // n_real % 4 == 0: the chunk holds 4 real columns
         } else {
             float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             const bool full = n + 8 <= a.n_real;
@@ -458,8 +474,8 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
             half_t* dst = a.C + (int64_t)m * a.ldc + n;
-            if (full) *(h8*)dst = o;
-            else *(h4*)dst = h4{o[0], o[1], o[2], o[3]};
+            if (full) g2_store_c<POL>(dst, o);
+            else g2_store_c<POL>(dst, h4{o[0], o[1], o[2], o[3]});
         }
         if (hh == 0) G2_EST(2); else G2_EST(4);          // this half's store is issued
     }
@@ -472,7 +488,7 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
 // store round trips per tile = 38-46 k cycles, whatever the activation (round 4, tools/gemm_lab/ts_probe.py: 40 % of a K = 1280 tile).
 // Now every residual vector of the tile is fetched up front into the registers the dead operand fragments leave free (16 x 16 bytes per
 // lane), one wait, and the 16 stores go out back to back.  (`out_rows` launches - the projector's last GEMM - take the direct epilogue.)
-template <int ACT, int STORES = 2, bool TS = false>
+template <int ACT, int STORES = 2, bool TS = false, int POL = 0>
 __device__ __forceinline__ void g2_epilogue_row_act(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem, int wfree, int afree,
                                                     unsigned long long* st = nullptr) {
     const int g = lane >> 4;
@@ -502,15 +518,15 @@ __device__ __forceinline__ void g2_epilogue_row_act(const GemmArgs& a, f4 (&acc)
             }
     }
     if constexpr (TS) asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[0])::"memory");     // bias + residual have landed
-    g2_epilogue_row_u<0, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab, TS ? st + 3 : nullptr);
+    g2_epilogue_row_u<0, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab, TS ? st + 3 : nullptr);
     if constexpr (TS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[1])::"memory");
-    g2_epilogue_row_u<1, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<2, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<3, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<4, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<5, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<6, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
-    g2_epilogue_row_u<7, ACT, STORES>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<1, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<2, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<3, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<4, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<5, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<6, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
+    g2_epilogue_row_u<7, ACT, STORES, POL>(a, acc, bias, res, mb, nb, lane, slab);
     if constexpr (TS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[2])::"memory");
 }
 // Which activation a projection TAG implies (launch_gemm256 only picks a tagged instantiation when the arguments agree; anything else
@@ -534,7 +550,7 @@ static int g2_tag_act(int tag) {
 template <int TAG>
 __device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem, int wfree, int afree,
                                                 unsigned long long* st = nullptr) {
-    g2_epilogue_row_act<G2TagAct<TAG>::act, G2Lab<TAG>::epi_nostore ? 0 : G2Lab<TAG>::epi_halfstore ? -1 : 2, G2Lab<TAG>::ts>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
+    g2_epilogue_row_act<G2TagAct<TAG>::act, G2Lab<TAG>::epi_nostore ? 0 : G2Lab<TAG>::epi_halfstore ? -1 : 2, G2Lab<TAG>::ts, G2Lab<TAG>::store_aux>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
 }
 
 template <int EPI, int TAG>
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const bool has_next = nxt < nwg;
         int bm2 = bm, bn2 = bn;
         if (has_next) tile_of(nxt, bm2, bn2);
-        unsigned long long tT0 = 0, tT1 = 0, tT2 = 0, tT3 = 0;
+        [[maybe_unused]] unsigned long long tT0 = 0, tT1 = 0, tT2 = 0, tT3 = 0;
         if constexpr (G2Lab<TAG>::ts) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tT0));
         const int wait = first ? 0 : (cont ? 2 : 1);
         if (vmode) g2_mainloop<EPI, true, TAG>(a, src, smem, acc, w, lane, wait, ap, wp, cont && has_next, bm2, bn2);
@@ -673,7 +689,8 @@ hipError_t gemm256_init() {
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 17>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 18>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 19>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 20>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 21>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 22>()) != hipSuccess ||
-        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 23>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 24>()) != hipSuccess)
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 23>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 24>()) != hipSuccess ||
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 25>()) != hipSuccess)
         return e;
 #endif
     return hipSuccess;
@@ -728,6 +745,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 22: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 22); break;
             case 23: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 23); break;
             case 24: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 24); break;
+            case 25: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 25); break;
             default: return hipErrorInvalidValue;
         }
 #endif

@@ -179,6 +179,8 @@ struct DecAttnArgs {
     half_t* out_f;          // [B, heads*hd] in x-fragment form (K32 = out_k32 = heads*hd/32)
     int out_k32;
     int variant;            // 0: load-use per page; 1: software-pipelined (next page's K + this page's V in flight)
+    int* cnt;               // [B][heads] arrival counters, zero between launches (variant 4, nsplit > 1): the split that finds its
+                            // (sequence, head) complete combines the partials IN the attention kernel; nullptr = decode_attn_combine_kernel follows
 };
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);            // main + combine
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s);

@@ -101,6 +101,8 @@ def parse():
                    "row, the rest for each sequence's last 128 rows only (bitwise the same outputs)")
     p.add_argument("--fused-reduce", type=int, default=-1, help="A/B: 0 (engine default) = the split-K residual projections (o, down) are followed by a reduce launch, 1 = "
                    "the reduce runs inside the projection kernel (bitwise the same outputs; measured no faster)")
+    p.add_argument("--attn-fused-combine", type=int, default=-1, help="A/B: 1 (engine default) = the last-arriving split of the VALU decode attention combines "
+                   "the partials in the kernel, 0 = decode_attn_combine_kernel follows as its own launch")
     p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
                                                             "launches short - rocprofv3's counter mode crashed with ~11 k launches queued ahead of the GPU)")
     p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "
@@ -404,6 +406,8 @@ def main():
         eng.set_option("prefill_prune_last", args.prune_last)
     if args.fused_reduce >= 0:
         eng.set_option("decode_fused_reduce", args.fused_reduce)
+    if args.attn_fused_combine >= 0:
+        eng.set_option("dec_attn_fused_combine", args.attn_fused_combine)
 
     # synthetic inputs, resident in HBM before the timed region.  Clip i of the job's world * B clips belongs to rank i % world - the
     # reference harness's round-robin `islice(docs, rank, None, world_size)` (lmms_eval/utils.py:675-681, aurora_amd.parallel.shard_clips).

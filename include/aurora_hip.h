@@ -200,6 +200,8 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 /* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 4 (default: v_dot2c page pipeline) / 1 (MFMA page pipeline) /
  * 3 (the same with two waves per SIMD) / 2 (default-policy K / V loads) / 0 (un-pipelined), "decode_fused_reduce" 0 (default: the split-K
  * residual projections are followed by a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same),
+ * "dec_attn_fused_combine" 0 (default: decode_attn_combine_kernel follows the split attention as its own launch) / 1 (the last-arriving
+ * split of a (sequence, head) combines in the attention kernel; bitwise the same, 0.3 % slower on 8-slot engines: DESIGN section 10),
  * "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),

@@ -386,3 +386,46 @@ def test_pruned_last_prefill_layer_is_bitwise_the_full_one(name, L, nseq):
     finally:
         eng.set_option("prefill_prune_last", 1)
         eng.close()
+
+
+@pytest.mark.parametrize("name,batch,ctx", [("hd128", 1, 900), ("hd128", 3, 500), ("hd64", 2, 300), ("hd32", 1, 200)])
+def test_in_kernel_attention_combine_is_bitwise_the_combine_kernel(name, batch, ctx):
+    """Engines whose batch alone does not fill the GPU run several splits per (sequence, head); since round 4 the split that finds
+    its pair complete (agent-scope arrival counter, write-through partials, sc1 loads) combines them IN decode_attn_dot_kernel, in the
+    fixed split order and with the same function as decode_attn_combine_kernel - whose launch disappears (32 of 225 per 8-slot step).
+    Same additions in the same order: ids and logits bit for bit, eager and as a hipGraph, repeated (a lost or early hand-over
+    would show as a different sum) with a second stream keeping the GPU busy, ragged contexts so that splits finish unevenly; the
+    arrival counters are back at zero after every launch (graph replays rely on it)."""
+    cfg = LLM_CFGS[name]
+    gen = torch.Generator().manual_seed(500 + batch)
+    lens = [ctx - 37 * b for b in range(batch)]
+    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
+    res = {}
+    for use_graph in (False, True):
+        eng, w = make_engine(cfg, 23, max_batch=batch, use_graph=use_graph, max_ctx=1024, max_new=16)
+        try:
+            noise = torch.randn(4096, 4096, device="cuda")
+            side = torch.cuda.Stream()
+            for fused in (0, 1, 1):
+                eng.set_option("dec_attn_fused_combine", fused)
+                with torch.cuda.stream(side):                      # a busy neighbour: uneven arrival of the splits
+                    for _ in range(20):
+                        noise = noise @ noise * 1e-4
+                eng.begin_batch(batch, 16, None)
+                for b in range(batch):
+                    eng.prefill(b, padded(embs[b]), lens[b])
+                logits = []
+                for _ in range(10):
+                    eng.decode(1)
+                    logits.append(eng.logits().clone())
+                cur = (eng.outputs(), torch.stack(logits))
+                side.synchronize()
+                if (use_graph, fused) in res:
+                    assert cur[0] == res[(use_graph, fused)][0] and torch.equal(cur[1], res[(use_graph, fused)][1])
+                res[(use_graph, fused)] = cur
+        finally:
+            eng.close()
+    base = res[(False, 0)]
+    for key, cur in res.items():
+        assert cur[0] == base[0], key
+        assert torch.equal(cur[1], base[1]), key
