@@ -78,7 +78,7 @@ struct aur_ctx {
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
     int attn_variant = 4, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option); decode attention: 4 = VALU dot products (decode.hip)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
-    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
+    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1, gemm_nt_out = -1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
     int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
@@ -144,6 +144,12 @@ static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t
     a.tile_order = ctx->gemm_tile_order;
     a.tail_split = ctx->gemm_tail_split;
     a.lab = ctx->gemm_lab;
+    // Output policy.  A round of 256x256 tiles writes 256 x 128 KiB in one burst (every CU reaches its epilogue together) - the capacity
+    // of the eight L2s; with the default policy that burst evicts the operand panels the next tiles share through L2.  Outputs the L2s
+    // could not hold for the consumer anyway go out non-temporal (round 4: ViT fc1 +8 %, prefill gate/up +3 %, QKV +2-3 %); a single
+    // clip's prefill (17-50 MB per projection, read back at once by the next launch) keeps the default (+1 % on its layer stack).
+    const int64_t out_cols = epi == EPI_QKV ? (int64_t)a.q_cols + 2 * a.k_cols : (a.act == ACT_SILU_MUL ? a.n_real / 2 : a.n_real);
+    a.nt_out = ctx->gemm_nt_out >= 0 ? ctx->gemm_nt_out : ((int64_t)a.M * out_cols * 2 > ((int64_t)32 << 20));
     return launch_gemm(a, epi, s);
 }
 
@@ -1276,6 +1282,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         // valid - the serving schedule changes gemm_max_wgs around every front end (caption_stream) while decode launches are queued
         if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
         else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
+        else if (!strcmp(name, "gemm_nt_out")) ctx->gemm_nt_out = value < 0 ? -1 : (value ? 1 : 0);
         else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
         else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value >= 0 && value <= 2) ? (int)value : 1;
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;

@@ -394,15 +394,16 @@ __device__ __forceinline__ void g2_mainloop(const GemmArgs& a, G2Src& src, char*
     do {                                                                                              \
         if (U == 0 && fine) asm volatile("s_memtime %0" : "=s"(fine[i])::"memory");                   \
     } while (0)
-// One output vector of the wide epilogue.  POL 2 (product): a non-temporal store.  Every round of tiles writes 256 x 128 KiB - the capacity of
+// One output vector of the wide epilogue.  POL 2 (product): a non-temporal store when the launch asks for it (GemmArgs.nt_out: outputs larger
+// than the L2s together; engine.hip ctx_gemm).  Every round of tiles writes 256 x 128 KiB - the capacity of
 // the eight L2s - in one burst, because all CUs reach their epilogue together; written with the default policy the output evicts the operand
 // panels the next tiles share through L2 and the K loops AFTER the epilogue pay for it (round 4, tools/gemm_lab/store_probe.py and
 // conc_probe.py: the per-tile fixed cost is 9.7 us with up to 128 CUs running and 16.4 us with 256; a K = 128 sweep 500 -> 310 us, K = 1280
 // 1180 -> 1085 us, prefill gate/up -3 %, with `nt`; sc1 / sc0 sc1 write-through stores gain less).  Nothing on this path re-reads C from L2:
 // the consumer is the next launch, and C is 40-800 MB.
 template <int POL, typename V>
-__device__ __forceinline__ void g2_store_c(half_t* dst, const V& v) {
-    if constexpr (POL == 2) __builtin_nontemporal_store(v, (V*)dst);
+__device__ __forceinline__ void g2_store_c(bool nt, half_t* dst, const V& v) {
+    if (POL == 2 && nt) __builtin_nontemporal_store(v, (V*)dst);
     else *(V*)dst = v;
 }
 template <int U, int ACT, int STORES = 2, int POL = 0>
@@ -461,8 +462,8 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
             o[2] = (half_t)(silu_f(x1[0]) * x1[1]);
             o[3] = (half_t)(silu_f(x1[2]) * x1[3]);
             half_t* dst = a.C + (int64_t)m * a.ldc + (n >> 1);
-            if (n + 8 <= a.n_real) g2_store_c<POL>(dst, o);
-            else g2_store_c<POL>(dst, h2{o[0], o[1]});             // n_real % 4 == 0: the chunk holds 4 real columns
+            if (n + 8 <= a.n_real) g2_store_c<POL>(a.nt_out != 0, dst, o);
+            else g2_store_c<POL>(a.nt_out != 0, dst, h2{o[0], o[1]});             // n_real % 4 == 0: the chunk holds 4 real columns
         } else {
             float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             const bool full = n + 8 <= a.n_real;
@@ -474,8 +475,8 @@ __device__ __forceinline__ void g2_epilogue_row_u(const GemmArgs& a, f4 (&acc)[4
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
             half_t* dst = a.C + (int64_t)m * a.ldc + n;
-            if (full) g2_store_c<POL>(dst, o);
-            else g2_store_c<POL>(dst, h4{o[0], o[1], o[2], o[3]});
+            if (full) g2_store_c<POL>(a.nt_out != 0, dst, o);
+            else g2_store_c<POL>(a.nt_out != 0, dst, h4{o[0], o[1], o[2], o[3]});
         }
         if (hh == 0) G2_EST(2); else G2_EST(4);          // this half's store is issued
     }

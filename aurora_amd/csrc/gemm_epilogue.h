@@ -6,6 +6,13 @@
 #pragma once
 #include "kernels.h"
 
+// Q fragments and K / V page fragments: written in one burst per round of tiles, read by the NEXT launch (attention).  nt: GemmArgs.nt_out
+template <typename V>
+__device__ __forceinline__ void qkv_store(bool nt, half_t* dst, const V& v) {
+    if (nt) __builtin_nontemporal_store(v, (V*)dst);
+    else *(V*)dst = v;
+}
+
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][TM], int mb, int nb, int lane, bool vmode) {
     const int r = lane & 15, g = lane >> 4;
@@ -94,12 +101,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
                     if (is_q) {
                         half_t* dst = a.Qf + ((((int64_t)seq * kv.heads + head) * T16 + (tok >> 4)) * kv.kblk + blk) * AUR_FRAG_HALVES +
                                       (g * 16 + (tok & 15)) * 8;
-                        *(h8*)dst = o;
+                        qkv_store(a.nt_out != 0, dst, o);
                     } else {
                         const int pos = a.pos0 + tok;
                         half_t* dst = kv_page(kv, a.seq0 + seq, pos) + kfrag_off(kv, head, (pos % kv.page_tokens) >> 4, blk) +
                                       (g * 16 + (pos & 15)) * 8;
-                        *(h8*)dst = o;
+                        qkv_store(a.nt_out != 0, dst, o);
                     }
                 }
             }
@@ -125,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
                     }
                     half_t* dst = kv_page(kv, a.seq0 + seq, pos) + vfrag_off(kv, head, d16, (pos % kv.page_tokens) >> 5) +
                                   (g * 16 + r) * 8;
-                    *(h8*)dst = o;
+                    qkv_store(a.nt_out != 0, dst, o);
                 }
             }
         }

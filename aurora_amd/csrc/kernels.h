@@ -35,6 +35,7 @@ struct GemmArgs {
     int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
     int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges,
                             // 2 = hand-down: an XCD keeps its band of M-tiles, weight column groups pass from XCD to XCD round by round
+    int nt_out;             // 1 = the output of this launch is larger than the L2s together: written with non-temporal stores (ctx_gemm)
     int lab;                // 0 in the product path; > 0 = lab instantiation of the 256x256 kernel (gemm256.hip G2Lab, EPI_ROW only)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent

@@ -204,6 +204,7 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * split of a (sequence, head) combines in the attention kernel; bitwise the same, 0.3 % slower on 8-slot engines: DESIGN section 10),
  * "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
+ * "gemm_nt_out" -1 (default: GEMM outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
  * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_ring", "gemm_tile_order" 1 (rounds of the persistent grid are
