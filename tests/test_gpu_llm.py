@@ -18,6 +18,14 @@ LLM_CFGS = {
     "hd128": dict(hidden_size=256, num_attention_heads=2, num_hidden_layers=3, intermediate_size=640, vocab_size=1000,
                   rms_norm_eps=1e-6, rope_theta=1e4, rope_factor=4.0),
 }
+# the greedy pick scans a row of logits with 1024 threads and 16-byte loads: a vocabulary that is not a multiple of 4 (scalar scan) and one
+# that takes more than one pass of the block
+LLM_CFGS_VOCAB = {
+    "v323": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=256, vocab_size=323,
+                 rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=1.0),
+    "v9000": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=256, vocab_size=9000,
+                  rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=1.0),
+}
 LOGIT_TOL = 3e-2       # max-abs, relative to max |logit|
 
 
@@ -59,10 +67,10 @@ def teacher_forced_logits(emb, ids, w, cfg):
     return torch.nn.functional.linear(h[emb.shape[0] - 1:], w["lm_head.weight"])
 
 
-@pytest.mark.parametrize("name", list(LLM_CFGS))
+@pytest.mark.parametrize("name", list(LLM_CFGS) + list(LLM_CFGS_VOCAB))
 @pytest.mark.parametrize("L", [40, 97])
 def test_prefill_and_stepwise_decode_logits(name, L):
-    cfg = LLM_CFGS[name]
+    cfg = LLM_CFGS.get(name) or LLM_CFGS_VOCAB[name]
     eng, w = make_engine(cfg, 5, max_batch=1, use_graph=False)
     try:
         gen = torch.Generator().manual_seed(L)
