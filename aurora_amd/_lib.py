@@ -61,6 +61,7 @@ SIGNATURES = {
     "aur_tome_r": (_I, [_I, _I, _I, C.c_double, _I]),
     "aur_tokens_at_layer": (_I, [_I, _I, _I]),
     "aur_vit_encode": (C.c_int, [_P, _P, _I, _I, _P, _IP, _P]),
+    "aur_vit_pos_interp": (C.c_int, [_P, _I, _I, _P, _P]),
     "aur_vit_encode_hw": (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _IP, _P]),
     "aur_project_splice": (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "aur_begin_batch": (C.c_int, [_P, _I, _I, _I, _P]),

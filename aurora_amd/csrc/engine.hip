@@ -668,6 +668,18 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     return AUR_OK;
 }
 
+extern "C" int aur_vit_pos_interp(aur_ctx* ctx, int32_t height, int32_t width, void* pos_out, void* stream) {
+    if (!ctx->finalized || ctx->vl.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_vit_pos_interp: vision weights not finalized");
+    const aur_config& g = ctx->cfg;
+    const int gh = height / g.vit_patch, gw = width / g.vit_patch;
+    if (gh < 1 || gw < 1 || !pos_out) return aur_fail(ctx, AUR_ERR_ARG, "aur_vit_pos_interp: input %dx%d, patch %d", height, width, g.vit_patch);
+    int n = 1;
+    while ((n + 1) * (n + 1) <= ctx->v_native_npatch) ++n;          // aurora.py:929-931: the native grid is square
+    if (n * n != ctx->v_native_npatch) return aur_fail(ctx, AUR_ERR_STATE, "aur_vit_pos_interp: the native table holds %d patch rows, not a square", ctx->v_native_npatch);
+    CK(launch_pos_interp(ctx->v_pos, n, gh, gw, g.vit_hidden, (half_t*)pos_out, (hipStream_t)stream));
+    return AUR_OK;
+}
+
 extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t height, int32_t width,
                                  const void* pos_emb, int32_t r, void* out_tokens, int32_t* n_kept_out, void* stream) {
     if (!ctx->finalized || ctx->vl.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_vit_encode: vision weights not finalized");

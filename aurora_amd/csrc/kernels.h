@@ -116,6 +116,7 @@ hipError_t launch_vit_assemble(const half_t* patches, const half_t* cls, const h
 hipError_t launch_strip_cls(const half_t* x, int frames, int t, int t_pad, int d, half_t* out, hipStream_t s);
 hipError_t launch_pad_rows(const half_t* src, const float* size_src, int frames, int t, int t_pad, int d, half_t* dst,
                            float* size_dst, hipStream_t s);
+hipError_t launch_pos_interp(const half_t* pos, int n, int gh, int gw, int d, half_t* out, hipStream_t s);
 hipError_t launch_unpad_rows(const half_t* src, const float* size_src, int frames, int t, int t_pad, int d, half_t* dst,
                              float* size_dst, hipStream_t s);
 hipError_t launch_gather_rows(const half_t* src, int ld_src, const int32_t* rows, int nrows, int d, half_t* dst,

@@ -197,3 +197,57 @@ hipError_t launch_unpad_rows(const half_t* src, const float* size_src, int frame
     hipLaunchKernelGGL(unpad_rows_kernel, dim3(t, frames), dim3(128), 0, s, src, size_src, t, t_pad, d, dst, size_dst);
     return hipGetLastError();
 }
+
+// ---- position table for a non-native patch grid (aurora.py:909-951) --------------------------------------------------------
+// The reference resamples the n x n patch rows of the checkpoint's table with
+//   F.interpolate(grid, scale_factor = ((gh + 0.1) / n, (gw + 0.1) / n), mode = "bicubic")
+// i.e. ATen's upsample_bicubic2d with align_corners = False and the GIVEN scale factors: the source coordinate of output index i is
+// (1 / scale) * (i + 0.5) - 0.5 with 1 / scale rounded to float once, taps floor(.) - 1 .. + 2 clamped to the grid, the cubic convolution
+// weights with A = -0.75, four taps along x per row first, then along y - the same expressions in the same order here, in fp32 on the fp16
+// table (the engine's stored table), one thread per (output row, feature).  Row 0 (class token) is copied.
+__device__ __forceinline__ float cubic_conv1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic_conv2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ void cubic_coeffs(float (&c)[4], float t) {
+    const float A = -0.75f;
+    c[0] = cubic_conv2(t + 1.f, A);
+    c[1] = cubic_conv1(t, A);
+    const float u = 1.f - t;
+    c[2] = cubic_conv1(u, A);
+    c[3] = cubic_conv2(u + 1.f, A);
+}
+__global__ void pos_interp_kernel(const half_t* __restrict__ pos, int n, int gh, int gw, int d, float inv_sy, float inv_sx,
+                                  half_t* __restrict__ out) {
+    const int row = blockIdx.x;                     // 0 = class row, 1 + oy * gw + ox
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        if (row == 0) {
+            out[c] = pos[c];
+            continue;
+        }
+        const int oy = (row - 1) / gw, ox = (row - 1) % gw;
+        const float ry = inv_sy * ((float)oy + 0.5f) - 0.5f, rx = inv_sx * ((float)ox + 0.5f) - 0.5f;
+        const float fy = floorf(ry), fx = floorf(rx);
+        const int iy = (int)fy, ix = (int)fx;
+        float cy[4], cx[4];
+        cubic_coeffs(cy, ry - fy);
+        cubic_coeffs(cx, rx - fx);
+        float rows[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = min(max(iy - 1 + k, 0), n - 1);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = min(max(ix - 1 + j, 0), n - 1);
+                v[j] = (float)pos[(int64_t)(1 + y * n + x) * d + c];
+            }
+            rows[k] = v[0] * cx[0] + v[1] * cx[1] + v[2] * cx[2] + v[3] * cx[3];
+        }
+        out[(int64_t)row * d + c] = (half_t)(rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3]);
+    }
+}
+hipError_t launch_pos_interp(const half_t* pos, int n, int gh, int gw, int d, half_t* out, hipStream_t s) {
+    // 1 / scale_factor as ATen takes it: computed in double from the Python floats, rounded to float once
+    const float inv_sy = (float)(1.0 / (((double)gh + 0.1) / (double)n)), inv_sx = (float)(1.0 / (((double)gw + 0.1) / (double)n));
+    hipLaunchKernelGGL(pos_interp_kernel, dim3(gh * gw + 1), dim3(d < 256 ? 64 * ((d + 63) / 64) : 256), 0, s, pos, n, gh, gw, d, inv_sy, inv_sx, out);
+    return hipGetLastError();
+}

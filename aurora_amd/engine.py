@@ -10,7 +10,6 @@ exactly like `oracle/aurora_oracle.py` consumes them, so parity tests feed both 
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -218,9 +217,8 @@ class AuroraCapEngine:
         rm[2 * qcols: 2 * qcols + D] = 2 * D + np.arange(D)
         self._set("vit.patch.w", self.pack(w["patch_embedding.weight"].reshape(D, -1), dpad, kpad))
         self._set("vit.cls", self._h(w["class_embedding"].reshape(-1)))
-        self._pos_native = self._h(w["position_embedding.weight"])       # kept for interpolated_pos()
-        self._pos_cache: Dict[tuple, torch.Tensor] = {}
-        self._set("vit.pos", self._pos_native)
+        self._pos_cache: Dict[tuple, torch.Tensor] = {}                  # interpolated_pos(): one table per input size
+        self._set("vit.pos", self._h(w["position_embedding.weight"]))
         self._set("vit.preln.w", self._f(w["pre_layrnorm.weight"]))
         self._set("vit.preln.b", self._f(w["pre_layrnorm.bias"]))
         nl = v["num_hidden_layers"] - 1          # hidden_states[-2]: the last layer is never needed
@@ -331,7 +329,7 @@ class AuroraCapEngine:
     def interpolated_pos(self, height: int, width: int) -> Optional[torch.Tensor]:
         """Position table for a non-native input size (aurora.py:909-951): the n x n patch rows of the checkpoint's table
         resampled bicubically to (height // patch, width // patch) with the reference's scale factors (g + 0.1) / n; None
-        for the native grid.  One-off weight preparation per input size (cached), done with torch on the device."""
+        for the native grid.  One launch per input size (`pos_interp_kernel`, vit.hip), cached."""
         v = self.v
         gh, gw = height // v["patch_size"], width // v["patch_size"]
         n = v["image_size"] // v["patch_size"]
@@ -339,13 +337,9 @@ class AuroraCapEngine:
             return None
         key = (gh, gw)
         if key not in self._pos_cache:
-            pos = self._pos_native.float()
-            grid = pos[1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
-            out = torch.nn.functional.interpolate(grid, scale_factor=((gh + 0.1) / math.sqrt(n * n), (gw + 0.1) / math.sqrt(n * n)),
-                                                  mode="bicubic")
-            assert out.shape[-2] == gh and out.shape[-1] == gw
-            tab = torch.cat([pos[:1], out.permute(0, 2, 3, 1).reshape(gh * gw, -1)], dim=0)
-            self._pos_cache[key] = tab.to(torch.float16).contiguous()
+            tab = torch.empty(1 + gh * gw, v["hidden_size"], dtype=torch.float16, device=self.dev)
+            check(self.ctx, self.L.aur_vit_pos_interp(self.ctx, height, width, tab.data_ptr(), self._stream()), "aur_vit_pos_interp")
+            self._pos_cache[key] = tab
         return self._pos_cache[key]
 
     def splice_plan(self, input_ids: Sequence[int], frames: int, n_kept, strict: bool = False):

@@ -105,8 +105,15 @@ int aur_vit_encode(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t r, 
 /* Same for inputs that are not vit_image x vit_image (AuroraEncoder.interpolate_pos_encoding,
  * aurora.py:909-951): pixels fp16 [frames, channels, height, width]; the patch grid is (height / patch) x (width / patch)
  * and must fit the ctx ((h/p)*(w/p) + 1 <= (vit_image/patch)^2 + 1; make vit_image larger than vit_native_image to admit bigger inputs).  pos_emb: fp16 [1 + (h/p)*(w/p), vit_hidden], the
- * position table the caller interpolated for this grid (bicubic, the reference's scale factors); NULL is allowed only
+ * position table of this grid (aur_vit_pos_interp; the engine caches one per input size); NULL is allowed only
  * for the native grid.  r is computed by the caller from height and width (aur_tome_r). */
+/* AuroraEncoder.interpolate_pos_encoding (aurora.py:909-951) for an input of height x width pixels: the n x n patch rows of the
+ * checkpoint's table ("vit.pos") resampled bicubically to (height / patch) x (width / patch) with the reference's scale factors
+ * (g + 0.1) / n - ATen's upsample_bicubic2d arithmetic (align_corners = False, A = -0.75), fp32 on the stored fp16 table - class row kept.
+ * pos_out: fp16 [1 + (height / patch) * (width / patch), vit_hidden], the table aur_vit_encode_hw takes.  Valid for the native grid
+ * too (it then reproduces the table up to the resampling's rounding; callers pass NULL to aur_vit_encode_hw instead). */
+int aur_vit_pos_interp(aur_ctx* ctx, int32_t height, int32_t width, void* pos_out, void* stream);
+
 int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t height, int32_t width,
                       const void* pos_emb, int32_t r, void* out_tokens, int32_t* n_kept_out, void* stream);
 
