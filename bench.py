@@ -103,6 +103,7 @@ def parse():
                    "the reduce runs inside the projection kernel (bitwise the same outputs; measured no faster)")
     p.add_argument("--gemm-nt-out", type=int, default=-1, help="A/B: GEMM output stores 0 = default cache policy, 1 = non-temporal, -1 (engine default) = non-temporal "
                    "for outputs larger than the L2s together")
+    p.add_argument("--dec-attn-pps", type=int, default=0, help="A/B: KV pages per decode-attention split (0 = the engine's choice: ~512 waves on the GPU)")
     p.add_argument("--attn-fused-combine", type=int, default=-1, help="A/B: 1 (engine default) = the last-arriving split of the VALU decode attention combines "
                    "the partials in the kernel, 0 = decode_attn_combine_kernel follows as its own launch")
     p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
@@ -410,6 +411,8 @@ def main():
         eng.set_option("decode_fused_reduce", args.fused_reduce)
     if args.gemm_nt_out >= 0:
         eng.set_option("gemm_nt_out", args.gemm_nt_out)
+    if args.dec_attn_pps > 0:
+        eng.set_option("dec_attn_pps", args.dec_attn_pps)
     if args.attn_fused_combine >= 0:
         eng.set_option("dec_attn_fused_combine", args.attn_fused_combine)
 
