@@ -187,44 +187,84 @@ template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][TM], int mb, int nb, int lane, bool vmode) {
     const int r = lane & 15, g = lane >> 4;
     if (EPI == EPI_ROW) {
+        // Every load of the region - output row map, bias, residual pieces - is issued before its first store and pinned there
+        // (`landed`): rounds 1-3 fetched bias and residual inside each of the TN x TM blocks, behind the previous block's store, and each such
+        // load waited for that store's round trip (see qkv_epilogue_qk).  Same arithmetic per element.
+        int orow[TM];
 #pragma unroll
         for (int u = 0; u < TM; ++u) {
             const int m = mb + u * 16 + r;
-            if (m >= a.M) continue;
-            const int orow = a.out_rows ? a.out_rows[m] : m;
-            if (orow < 0) continue;
+            orow[u] = m >= a.M ? -1 : (a.out_rows ? a.out_rows[m] : m);
+        }
+        f4 bias[TN];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const int n = nb + t * 16 + 4 * g;
-                if (n >= a.n_real) continue;
-                float v[4];
+        for (int t = 0; t < TN; ++t) {
+            const int n = nb + t * 16 + 4 * g;
+            bias[t] = f4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && n < a.n_real) {              // bias holds Npad >= n + 4 entries; columns past n_real are never stored
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[t][u][i] + (a.bias ? a.bias[n + i] : 0.f);
-                if (a.act == ACT_SILU_MUL) {
-                    h2 o;
-                    o[0] = (half_t)(silu_f(v[0]) * v[1]);
-                    o[1] = (half_t)(silu_f(v[2]) * v[3]);
-                    *(h2*)(a.C + (int64_t)orow * a.ldc + (n >> 1)) = o;
-                } else {
-                    if (a.act == ACT_QUICK_GELU) {
+                for (int i = 0; i < 4; ++i) bias[t][i] = a.bias[n + i];
+            }
+        }
+        const bool with_res = a.resid && a.act != ACT_SILU_MUL;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
-                    } else if (a.act == ACT_GELU) {
+        for (int u = 0; u < TM; ++u) landed(orow[u]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
-                    } else if (a.act >= ACT_SILU) {
+        for (int t = 0; t < TN; ++t) landed(bias[t]);
+        // residual pieces: four row blocks at a time (16 x 8 bytes per lane; all eight would spill the 256x256 kernel's registers)
+        constexpr int UH = TM > 4 ? 4 : TM;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+        for (int u0 = 0; u0 < TM; u0 += UH) {
+            h4 res[UH][TN];
+            if (with_res) {
+#pragma unroll
+                for (int uu = 0; uu < UH; ++uu)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const int m = min(mb + (u0 + uu) * 16 + r, a.M - 1), n = min(nb + t * 16 + 4 * g, a.n_real - 4);      // clamped: loads need no branch
+                        res[uu][t] = *(const h4*)(a.resid + (int64_t)m * a.ldr + n);
                     }
-                    if (a.resid) {
-                        const h4 rr = *(const h4*)(a.resid + (int64_t)m * a.ldr + n);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+                for (int uu = 0; uu < UH; ++uu)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) landed(res[uu][t]);
+            }
+#pragma unroll
+            for (int uu = 0; uu < UH; ++uu) {
+                const int u = u0 + uu;
+                if (orow[u] < 0) continue;
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const int n = nb + t * 16 + 4 * g;
+                    if (n >= a.n_real) continue;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[t][u][i] + bias[t][i];
+                    if (a.act == ACT_SILU_MUL) {
+                        h2 o;
+                        o[0] = (half_t)(silu_f(v[0]) * v[1]);
+                        o[1] = (half_t)(silu_f(v[2]) * v[3]);
+                        *(h2*)(a.C + (int64_t)orow[u] * a.ldc + (n >> 1)) = o;
+                    } else {
+                        if (a.act == ACT_QUICK_GELU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
+                        } else if (a.act == ACT_GELU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
+                        } else if (a.act >= ACT_SILU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+                        }
+                        if (with_res) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += (float)res[uu][t][i];
+                        }
+                        h4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+                        *(h4*)(a.C + (int64_t)orow[u] * a.ldc + n) = o;
                     }
-                    h4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
-                    *(h4*)(a.C + (int64_t)orow * a.ldc + n) = o;
                 }
             }
         }
