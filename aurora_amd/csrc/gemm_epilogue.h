@@ -211,8 +211,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
         for (int u = 0; u < TM; ++u) landed(orow[u]);
 #pragma unroll
         for (int t = 0; t < TN; ++t) landed(bias[t]);
-        // residual pieces: four row blocks at a time (16 x 8 bytes per lane; all eight would spill the 256x256 kernel's registers)
-        constexpr int UH = TM > 4 ? 4 : TM;
+        // residual pieces: all row blocks of the 128x128 kernel at once, two at a time in the 256x256 kernel (its direct path is the fallback of the wide epilogue - the projector's row-mapped last GEMM - and has 128 accumulators live: more would spill)
+        constexpr int UH = TM > 4 ? 2 : TM;
 #pragma unroll
         for (int u0 = 0; u0 < TM; u0 += UH) {
             h4 res[UH][TN];
