@@ -99,6 +99,14 @@ def main():
     for name, M, K, N in shapes[:1] + shapes[3:]:
         for lab in (10,):
             run(name, M, K, N, lab)
+    # quiet chip against full chip: the same stamped kernel on 8 workgroups (one per XCD) and on 256, 25 tiles per workgroup
+    # (profiles/r04_gemm_segments_quiet_vs_full.log: the same cycles per phase, 2.34 against 1.92 GHz)
+    for G in (8, 256):
+        eng.set_option("gemm_max_wgs", G)
+        print(f"\n==== {G} workgroups x 25 tiles (M = {320 * G}, N = 5120)")
+        for K in (1280, 4096):
+            run(f"K sweep shape, {G} CUs", 320 * G, K, 5120, 10)
+    eng.set_option("gemm_max_wgs", 0)
     eng.close()
 
 
