@@ -1300,7 +1300,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
         else if (!strcmp(name, "gemm_lab")) {
 #ifdef AUR_LABS
-            ctx->gemm_lab = (value >= 0 && value <= 25) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
+            ctx->gemm_lab = (value >= 0 && value <= 26) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
 #else
             return aur_fail(ctx, AUR_ERR_ARG, "gemm_lab exists in AUR_LABS builds only (python -m aurora_amd.build --labs)");
 #endif

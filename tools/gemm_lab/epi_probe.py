@@ -57,7 +57,7 @@ def main():
         tiles = t[:, :, 25].sum()
         epi, loop, blocks = t[:, :, 24].sum() / tiles, t[:, :, 21].sum() / tiles, t[:, :, 28].sum() / tiles
         ghz = (t[:, :, 22].sum() + t[:, :, 23].sum() + t[:, :, 24].sum()) / tiles / (us / tiles_per_wg * 1e3)
-        print(f"  G {G:3d}  K {K:5d}  N {N:5d}  {'no stores' if lab == 20 else 'continuous' if lab == 23 else 'stores   '}  tile {us / tiles_per_wg:7.1f} us  K loop {loop:8.0f}  "
+        print(f"  G {G:3d}  K {K:5d}  N {N:5d}  {'no stores' if lab == 20 else 'continuous' if lab == 23 else 'no operand DMA' if lab == 14 else 'lean epilogue' if lab == 26 else 'stores   '}  tile {us / tiles_per_wg:7.1f} us  K loop {loop:8.0f}  "
               f"epilogue {epi:7.0f} cycles (row blocks 1-7: {blocks:6.0f})  ~{ghz:4.2f} GHz", flush=True)
         eng.set_option("gemm_lab", 0)
 
@@ -71,6 +71,10 @@ def main():
             run(G, 25, K, 256, 10)
         for K in (1280, 4096):           # lab 23: the continuous pipeline - no prologue burst in front of the epilogue
             run(G, 25, K, 5120, 23)
+        for K in (256, 1280, 2560, 4096, 8192):     # lab 26: a compile-time activation = the product's 7.5 KB epilogue (the others: 78 KB)
+            run(G, 25, K, 5120, 26)
+        for K in (1280, 2560, 4096, 8192):     # lab 14: no operand DMA at all - the same MFMA bursts for the same time, nothing streamed
+            run(G, 25, K, 5120, 14)
     eng.set_option("gemm_max_wgs", 0)
     eng.set_option("gemm_mode", 1)
     eng.close()

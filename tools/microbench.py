@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--nseq", type=int, default=1, help="sequences per prefill pass for the pre_* kernels (<= batch)")
+    ap.add_argument("--ab-option", type=str, default="", help="A/B an engine option (0 / 1 / 0 / 1) on the prefill projections, e.g. gemm_nt_out")
     ap.add_argument("--half-grid", action="store_true", help="decode projections with half as many workgroups (decode_half_grid)")
     ap.add_argument("--mask-cus", type=int, default=0, help="time the kernels on a stream restricted to this many CUs of every XCD")
     args = ap.parse_args()
@@ -96,6 +97,10 @@ def main():
         eng.set_option("gemm_wide_epilogue", wide)
         run(tag, ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
     eng.set_option("gemm_mode", 1)
+    if args.ab_option:
+        for v in (0, 1, 0, 1):
+            eng.set_option(args.ab_option, v)
+            run(f"{args.ab_option} = {v}", ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
     if not args.quick:
         eng.set_option("dec_attn_variant", 1)
         for pps in (19, 38, 64):
