@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 
     // ------------------------------------------------------------------ epilogues (shared with the 256x256 kernel: the two agree bit for bit)
-    gemm_epilogue<EPI, 4, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, vmode);
+    if (EPI == EPI_ROW && a.act == ACT_NONE) gemm_epilogue<EPI, 4, 4, ACT_NONE>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, vmode);
+    else if (EPI == EPI_ROW && a.act == ACT_QUICK_GELU) gemm_epilogue<EPI, 4, 4, ACT_QUICK_GELU>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, vmode);
+    else if (EPI == EPI_ROW && a.act == ACT_SILU_MUL) gemm_epilogue<EPI, 4, 4, ACT_SILU_MUL>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, vmode);
+    else gemm_epilogue<EPI, 4, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, vmode);
 }
 
 hipError_t gemm_init() {

@@ -183,9 +183,14 @@ __device__ __forceinline__ void qkv_epilogue_v(const GemmArgs& a, f4 (&acc)[TN][
     }
 }
 
-template <int EPI, int TN, int TM>
+// ACTC: the activation as a compile-time constant, or -2 = read a.act at run time.  The run-time ladder is inlined into each of the TN x TM
+// blocks (erf-GELU alone is ~40 instructions per element): 56 KB of epilogue in the 128x128 kernel, of which a launch executes a scattered
+// fraction - instruction fetch, not arithmetic, then sets its time (gemm256.hip g2_epilogue_row, tools/gemm_lab/epi_probe.py).  The callers
+// dispatch the common activations to their own lean copy once per tile.
+template <int EPI, int TN, int TM, int ACTC = -2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][TM], int mb, int nb, int lane, bool vmode) {
     const int r = lane & 15, g = lane >> 4;
+    const int act = ACTC == -2 ? a.act : ACTC;
     if (EPI == EPI_ROW) {
         // Every load of the region - output row map, bias, residual pieces - is issued before its first store and pinned there
         // (`landed`): rounds 1-3 fetched bias and residual inside each of the TN x TM blocks, behind the previous block's store, and each such
@@ -206,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
                 for (int i = 0; i < 4; ++i) bias[t][i] = a.bias[n + i];
             }
         }
-        const bool with_res = a.resid && a.act != ACT_SILU_MUL;
+        const bool with_res = a.resid && act != ACT_SILU_MUL;
 #pragma unroll
         for (int u = 0; u < TM; ++u) landed(orow[u]);
 #pragma unroll
@@ -240,21 +245,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f4 (&acc)[TN][T
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = acc[t][u][i] + bias[t][i];
-                    if (a.act == ACT_SILU_MUL) {
+                    if (act == ACT_SILU_MUL) {
                         h2 o;
                         o[0] = (half_t)(silu_f(v[0]) * v[1]);
                         o[1] = (half_t)(silu_f(v[2]) * v[3]);
                         *(h2*)(a.C + (int64_t)orow[u] * a.ldc + (n >> 1)) = o;
                     } else {
-                        if (a.act == ACT_QUICK_GELU) {
+                        if (act == ACT_QUICK_GELU) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = quick_gelu_f(v[i]);
-                        } else if (a.act == ACT_GELU) {
+                        } else if (act == ACT_GELU) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
-                        } else if (a.act >= ACT_SILU) {
+                        } else if (act >= ACT_SILU) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], a.act);
+                            for (int i = 0; i < 4; ++i) v[i] = act_other_f(v[i], act);
                         }
                         if (with_res) {
 #pragma unroll
