@@ -218,6 +218,33 @@ def test_gemm256_equals_gemm128_bitwise_per_element_order(eng):
     assert torch.equal(o128, o256)
 
 
+def test_gemm_output_cache_policy_changes_no_bit(eng):
+    """`gemm_nt_out`: outputs larger than the L2s together leave with non-temporal stores (engine default), 0 / 1 force either policy -
+    a cache policy only: plain, activation (the generic kernel's ladder copy), residual and no-bias launches of both tile kernels are
+    bit-identical, ragged M and N included; and the generic kernel's lean epilogue copy (act == none) equals the 128x128 kernel's."""
+    from aurora_amd._lib import AUR_ACT_GELU
+    g = torch.Generator().manual_seed(102)
+    m, k, n = 1900, 320, 1000                                        # 8 x 4 tiles of 256, n_real % 256 != 0
+    a = (torch.randn(m, k, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, generator=g) * 0.05).half()
+    b = (torch.randn(n, generator=g) * 0.1).half()
+    res = torch.randn(m, n, generator=g).half()
+    outs = {}
+    try:
+        for mode in (0, 2):
+            eng.set_option("gemm_mode", mode)
+            for nt in (0, 1, -1):
+                eng.set_option("gemm_nt_out", nt)
+                outs[(mode, nt)] = (eng.linear(a, w, b), eng.linear(a, w, None), eng.linear(a, w, b, act=AUR_ACT_GELU), eng.linear(a, w, b, resid=res))
+    finally:
+        eng.set_option("gemm_nt_out", -1)
+        eng.set_option("gemm_mode", 1)
+    ref = outs[(0, 0)]
+    for key, cur in outs.items():
+        for x, y in zip(ref, cur):
+            assert torch.equal(x, y), key
+
+
 def test_gemm256_persistent_tiles_bitwise(eng):
     """gemm_max_wgs: a fixed number of workgroups walks all 256x256 tiles (used to confine the GEMM to a CU subset when
     two streams share the GPU) - results must not change by a bit, ragged M included."""
