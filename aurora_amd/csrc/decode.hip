@@ -34,6 +34,21 @@ __device__ __forceinline__ int64_t xfrag_piece(int b, int k, int K32) {
     return ((((int64_t)(b >> 4) * K32 + (k >> 5)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8;
 }
 
+// Lane whose 16-byte piece of an x fragment this lane loads for column group nb.  A lane whose batch row lies outside the live range
+// [b_lo, b_hi) reads the piece of a LIVE row of its group instead of its own: the same address as that lane, so the wave's request
+// touches only the live rows' 64-byte sectors - at one live row 4 x 16 bytes of a 1 KiB fragment instead of all of it.  (Measured at one
+// slot, round 5: the o and down projections read as many x bytes as weight bytes, 128 KiB resp. 344 KiB of mostly-zero rows per
+// workgroup through the same vector-memory path as the HBM stream.)  The MFMA columns of a dead row then hold a copy of a live row's
+// products; columns are independent and skinny_store never stores a dead one, so every live output keeps its bits whatever the batch.
+__device__ __forceinline__ int xsrc_lane(const SkinnyArgs& a, int lane, int nb) {
+    const int c = lane & 15;
+    int lo = a.b_lo - nb * 16, hi = a.b_hi - nb * 16;            // live columns of this group: [lo, hi) clipped to [0, 16)
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 16 ? 16 : hi;
+    const int cc = lo >= hi ? 0 : (c < lo ? lo : (c >= hi ? hi - 1 : c));
+    return (lane & ~15) | cc;
+}
+
 #define SSQ_SCALE 268435456.0f      /* 2^28 */
 // sum(x^2) accumulators are striped over AUR_SSQ_SLOTS copies, [slot][AUR_MAX_BATCH]: the residual-producing epilogues add into
 // slot (n16 tile % SLOTS), so the 256 integer atomics that hit one row's accumulator per projection spread over 16 L2 lines
@@ -198,14 +213,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_kernel(SkinnyArgs a) {
 
     // ONE continuous software pipeline over this wave's k32 tiles: U tiles of W (and x) fragments in registers,
     // the next U in flight.
-    constexpr int U = 4;
+    constexpr int U = 4;                         // (round 5: 8 is slower at 1-2 column groups: o 7.8 -> 8.0, down 17.3 -> 17.7, gate/up 31.7 -> 35.2 us at one slot)
     const int nit = a.K / (32 * NW);
     const half_t* wp[NT];
     const half_t* xp[NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wp[t] = a.W + ((int64_t)(tile0 + t) * K32 + w) * AUR_FRAG_HALVES + lane * 8;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) xp[nb] = a.xf + ((int64_t)nb * K32 + w) * AUR_FRAG_HALVES + lane * 8;
+    for (int nb = 0; nb < NB; ++nb) xp[nb] = a.xf + ((int64_t)nb * K32 + w) * AUR_FRAG_HALVES + xsrc_lane(a, lane, nb) * 8;
     constexpr int64_t STEP = (int64_t)NW * AUR_FRAG_HALVES;
     const int nfull = nit / U * U;
     int i0 = 0;
@@ -419,6 +434,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         // on all CUs), QKV loses (60.7 -> 64.6 us), gate/up does not care
         if constexpr (MODE == SK_ROW) __builtin_amdgcn_s_setprio(3);
         const int lw = w - NCW;
+        const int xl = NB == 1 ? xsrc_lane(a, lane, 0) : lane;   // one column group: dead rows re-read a live row's piece (see xsrc_lane)
         auto issue = [&](int ci) {
             char* buf = smem + (ci % NBUF) * CHUNK_BYTES;
 #pragma unroll
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
                 const int piece = q * NL + lw, kk = piece / NB, nb = piece % NB;
                 int kr = ci * KC + kk;
                 kr = kr < KE ? kr : KE - 1;                    // always PIECES instructions per chunk: the vmcnt below counts them
-                glds16(a.xf + ((int64_t)nb * K32 + kb + kr) * AUR_FRAG_HALVES + lane * 8, buf + piece * 1024);
+                glds16(a.xf + ((int64_t)nb * K32 + kb + kr) * AUR_FRAG_HALVES + xl * 8, buf + piece * 1024);
             }
         };
         int next = 0;
@@ -736,6 +752,7 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
                 if (half && (pairs & 1) == 0) return launch_skx_t<6, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs / 2, 1), s);
                 if (a.ring == 1) return launch_skx_t<3, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
             }
+            // (round 5: U = 8 at one column group - twice the weight bytes in flight per wave - is SLOWER: 20.1 -> 22.5 us at one slot)
             return launch_skx_t<3, 2, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
         case SK_SILU_MUL:
@@ -1296,14 +1313,38 @@ template <bool AGENT>
 __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b, int head, int d) {
     const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
     float M = -INFINITY;
-    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2));
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) {
-        const float m = attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2);
-        if (m == -INFINITY) continue;
-        const float wgt = __builtin_amdgcn_exp2f(m - M);
-        num = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_o + (p0 + s) * a.hd + d), num);
-        den = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2 + 1), den);
+    if (a.nsplit <= 16) {
+        // the engine's split counts (<= 16): every partial is fetched before the first is used - 3 x nsplit independent loads, one round
+        // trip - then the same operations in the same order as the loop below (rounds 1-4 ran that loop for every count: 2 x nsplit
+        // DEPENDENT round trips, 6.4 us per launch at one slot where the attention itself takes 8.9 us)
+        float m[16], l[16], o[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int sc = s < a.nsplit ? s : a.nsplit - 1;
+            m[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2);
+            l[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2 + 1);
+            o[s] = attn_part_ld<AGENT>(a.part_o + (p0 + sc) * a.hd + d);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < a.nsplit) M = fmaxf(M, m[s]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s >= a.nsplit || m[s] == -INFINITY) continue;
+            const float wgt = __builtin_amdgcn_exp2f(m[s] - M);
+            num = __builtin_fmaf(wgt, o[s], num);
+            den = __builtin_fmaf(wgt, l[s], den);
+        }
+    } else {
+        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2));
+        for (int s = 0; s < a.nsplit; ++s) {
+            const float m = attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2);
+            if (m == -INFINITY) continue;
+            const float wgt = __builtin_amdgcn_exp2f(m - M);
+            num = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_o + (p0 + s) * a.hd + d), num);
+            den = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2 + 1), den);
+        }
     }
     const int k = head * a.hd + d;                 // attention output in x-fragment form (input of the o projection)
     a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);

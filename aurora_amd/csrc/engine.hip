@@ -65,7 +65,6 @@ struct aur_ctx {
     // workspace regions (vision)
     half_t *w_col, *w_patch, *w_xa, *w_xb, *w_xn, *w_qf, *w_kv, *w_attn, *w_h;
     float *w_metric, *w_mhat, *w_nmax, *w_sza, *w_szb;
-    int32_t* w_tome_cnt;             // [max_frames] arrival counters of the ToMe match + select launch (zero between launches)
     int32_t *w_nidx, *w_unm, *w_src, *w_dst;
     // workspace regions (llm)
     half_t *l_xn, *l_qf, *l_attn, *l_h, *l_p1, *d_x, *d_q, *d_attn, *d_h, *d_scr;
@@ -84,6 +83,7 @@ struct aur_ctx {
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
     int* d_attn_cnt = nullptr;                                                  // [max_batch][heads] arrival counters of the decode attention's in-kernel combine
+    int tome_fused_ln = 1;                                                      // 1: LayerNorm 2 of a merging ViT layer comes out of the ToMe merge launch (bitwise norm_kernel's result; 0 = its own launch, A/B and test only)
     int attn_fused_combine = 0;                                                 // 1: the last-arriving split of a (sequence, head) combines in the attention kernel (bitwise the same; measured 0.3 % slower at 8 slots than the launch it saves)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
@@ -245,10 +245,9 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->w_attn = k.take<half_t>(F * TP * D);
     c->w_h = k.take<half_t>(F * TP * g.vit_mlp);
     c->w_metric = k.take<float>(F * c->v_t0 * c->v_hd);
-    c->w_mhat = k.take<float>(F * c->v_t0 * c->v_hd);
+    c->w_mhat = k.take<float>(F * tome_mfrag_floats(c->v_t0, c->v_hd));          // fp32 MFMA operand blocks (tome.hip)
     const int64_t ta = (c->v_t0 + 1) / 2;
     c->w_nmax = k.take<float>(F * ta);
-    c->w_tome_cnt = k.take<int32_t>(F);
     c->w_nidx = k.take<int32_t>(F * ta);
     c->w_unm = k.take<int32_t>(F * ta);
     c->w_src = k.take<int32_t>(F * ta);
@@ -364,8 +363,6 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     ctx->ws_bytes = n;
     carve(ctx, ctx->ws);
     ctx->finalized = false;
-    // arrival counters of the ToMe match + select launch: zero now, and every launch leaves them at zero
-    if (ctx->w_tome_cnt) CK(hipMemset(ctx->w_tome_cnt, 0, (size_t)ctx->cfg.max_frames * 4));
     if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
     if (ctx->d_attn_cnt) CK(hipMemset(ctx->d_attn_cnt, 0, (size_t)ctx->cfg.max_batch * ctx->cfg.llm_heads * 4));
     return AUR_OK;
@@ -637,15 +634,18 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
     half_t* xc = x;
     const float* sc = size;
     int t2 = t;
+    bool ln2_done = false;
     if (rl > 0) {
         TomeArgs ta{};
         t2 = t - rl;
         ta.frames = F; ta.t = t; ta.t_pad = t_pad; ta.r = rl; ta.c = ctx->v_hd; ta.d = D;
         ta.kv = &q.kv; ta.metric_out = want_metric ? ctx->w_metric : nullptr;             // metric = mean_h K, aurora.py:639
-        ta.counters = ctx->w_tome_cnt;
         ta.x = x; ta.size = size; ta.t_out_pad = rup(t2, 32); ta.x_out = x_alt; ta.size_out = size_alt;
         ta.node_max = ctx->w_nmax; ta.node_idx = ctx->w_nidx; ta.unm = ctx->w_unm; ta.src = ctx->w_src; ta.dst = ctx->w_dst;
         ta.mhat = ctx->w_mhat;
+        // LayerNorm 2 (aurora.py:750, eps :711) of the merged rows comes out of the merge launch (tome.hip: bitwise norm_kernel<false>)
+        ln2_done = ctx->tome_fused_ln && (D & 7) == 0;
+        if (ln2_done) { ta.ln_w = w.ln2_w; ta.ln_b = w.ln2_b; ta.ln_eps = 1e-5f; ta.ln_out = ctx->w_xn; }
         if (ctx->prof) kev_begin(ctx->kev[2], s);
         CK(launch_tome_step(ta, s));                                                       // aurora.py:746-747
         if (ctx->prof) kev_end(ctx->kev[2], s);
@@ -653,7 +653,7 @@ static int vit_layer_run(aur_ctx* ctx, int l, int F, int t, int r, half_t* x, co
         sc = size_alt;
     }
     const int t2_pad = rup(t2, 32), M2 = F * t2_pad;
-    CK(launch_layernorm(xc, D, w.ln2_w, w.ln2_b, 1e-5f, M2, D, ctx->w_xn, D, s));         // aurora.py:750
+    if (!ln2_done) CK(launch_layernorm(xc, D, w.ln2_w, w.ln2_b, 1e-5f, M2, D, ctx->w_xn, D, s));         // aurora.py:750
     GemmArgs f1{};
     f1.A = ctx->w_xn; f1.lda = D; f1.W = w.fc1_w; f1.bias = w.fc1_b; f1.M = M2; f1.Npad = ctx->v_mlp_pad; f1.K = D;
     f1.C = ctx->w_h; f1.ldc = g.vit_mlp; f1.n_real = g.vit_mlp; f1.act = g.vit_act == AUR_ACT_GELU ? ACT_GELU : ACT_QUICK_GELU; f1.tag = GT_VIT_FC1;
@@ -695,9 +695,6 @@ extern "C" int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frame
     hipStream_t s = (hipStream_t)stream;
     stage_begin(ctx, "vit", s);
     const int D = g.vit_hidden;
-    // arrival counters of the ToMe match + select launches: a launch leaves them at zero, but an aborted one (device fault, a
-    // caller that destroyed the stream mid-encode) would not - start every encode from a known state (4 bytes per frame)
-    CK(hipMemsetAsync(ctx->w_tome_cnt, 0, (size_t)g.max_frames * 4, s));
     CK(launch_im2col((const half_t*)pixels, frames, g.vit_channels, height, width, g.vit_patch, ctx->v_kpad, ctx->w_col, s));
     GemmArgs pe{};
     pe.A = ctx->w_col; pe.lda = ctx->v_kpad; pe.W = ctx->v_patch_w; pe.bias = nullptr; pe.M = frames * npatch;
@@ -779,7 +776,8 @@ extern "C" int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, c
     }
     const int64_t ta = (t + 1) / 2;
     // scratch must fit the ctx workspace regions sized for the configured ViT
-    if ((int64_t)frames * t * c > (int64_t)ctx->cfg.max_frames * ctx->v_t0 * ctx->v_hd || (int64_t)frames * ta > (int64_t)ctx->cfg.max_frames * ((ctx->v_t0 + 1) / 2) ||
+    if (c > 128) return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: at most 128 metric channels (got %d)", c);
+    if ((int64_t)frames * tome_mfrag_floats(t, c) > (int64_t)ctx->cfg.max_frames * tome_mfrag_floats(ctx->v_t0, ctx->v_hd) || (int64_t)frames * ta > (int64_t)ctx->cfg.max_frames * ((ctx->v_t0 + 1) / 2) ||
         (int64_t)frames * rup(t, 32) * d > (int64_t)ctx->cfg.max_frames * ctx->v_t0pad * ctx->cfg.vit_hidden)
         return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: problem larger than the workspace configured at aur_create");
     const int t_pad = rup(t, 32), t2 = t - rl, t2_pad = rup(t2, 32);
@@ -788,7 +786,6 @@ extern "C" int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, c
     a.frames = frames; a.t = t; a.t_pad = t_pad; a.r = rl; a.c = c; a.d = d; a.metric = metric; a.x = ctx->w_xa;
     a.size = size ? ctx->w_sza : nullptr; a.t_out_pad = t2_pad; a.x_out = ctx->w_xb; a.size_out = ctx->w_szb;
     a.node_max = ctx->w_nmax; a.node_idx = ctx->w_nidx; a.unm = ctx->w_unm; a.src = ctx->w_src; a.dst = ctx->w_dst; a.mhat = ctx->w_mhat;
-    a.counters = ctx->w_tome_cnt;
     CK(launch_tome_step(a, s));
     CK(launch_unpad_rows(ctx->w_xb, ctx->w_szb, frames, t2, t2_pad, d, (half_t*)x_out, size_out, s));
     if (node_idx) CK(hipMemcpyAsync(node_idx, ctx->w_nidx, (size_t)frames * ta * 4, hipMemcpyDeviceToDevice, s));
@@ -1281,6 +1278,10 @@ extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
 extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "prefill_prune_last")) {          // 1 (default): the last prefill layer computes Q / attention / MLP for each sequence's last 128 rows only
         ctx->prune_last = value ? 1 : 0;
+        return AUR_OK;
+    }
+    if (!strcmp(name, "tome_fused_ln")) {
+        ctx->tome_fused_ln = value ? 1 : 0;
         return AUR_OK;
     }
     if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;

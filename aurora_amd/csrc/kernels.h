@@ -98,12 +98,18 @@ struct TomeArgs {
     int32_t* unm;
     int32_t* src;
     int32_t* dst;
-    float* mhat;                     // scratch [frames][t][c] normalised metric
-    int32_t* counters;               // [frames] zero-initialised arrival counters of the match + select launch (left at zero)
+    float* mhat;                     // scratch: the normalised metric as fp32 MFMA operand blocks, tome_mfrag_floats(t, c) per frame
     const KvLayout* kv;              // non-null: metric = mean over heads of these K fragments (aurora.py:639), `metric` unused
     float* metric_out;               // with kv: optional copy of the un-normalised metric [frames][t][c]
+    // optional LayerNorm of the merged rows (aurora.py:750), written beside x_out from the merge launch: y = LN(x_out) as
+    // norm_kernel<false> computes it (bitwise), all frames * t_out_pad rows.  ln_out == nullptr: none.  Needs d % 8 == 0.
+    const float* ln_w;
+    const float* ln_b;
+    float ln_eps;
+    half_t* ln_out;                  // [frames][t_out_pad][d]
 };
 hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s);
+int64_t tome_mfrag_floats(int t, int c);          // floats of TomeArgs.mhat per frame
 // metric[f][tok][d] = mean over heads of K (read back from PAIRED K fragments of the ViT "pages")
 hipError_t launch_tome_metric(const KvLayout& kv, int frames, int t, int hd, float* metric, hipStream_t s);
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const half_t* __restrict__ x,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v[i][j] = (float)t[j];
-                s += RMS ? v[i][j] * v[i][j] : v[i][j];
+                s = RMS ? __builtin_fmaf(v[i][j], v[i][j], s) : s + v[i][j];
             }
         }
     }
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const half_t* __restrict__ x,
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float dlt = v[i][j] - mean;
-                    q += dlt * dlt;
+                    q = __builtin_fmaf(dlt, dlt, q);                    // explicit: tome.hip (built with -ffp-contract=off) repeats this row bit for bit
                 }
             }
         }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const half_t* __restrict__ x,
                     // HF: weight * hidden.to(input_dtype): round the normalised value to fp16 first
                     t = (w ? w[k] : 1.0f) * (float)(half_t)t;      // w == nullptr: weight folded into the consumer
                 } else {
-                    t = t * w[k] + b[k];
+                    t = __builtin_fmaf(t, w[k], b[k]);
                 }
                 o[j] = (half_t)t;
             }

@@ -98,3 +98,66 @@ class DistShim:
     def wait_for_everyone(self) -> None:
         if self.num_processes > 1:
             self._dist.barrier()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Host placement.  On N ranks the host is the shared resource: every rank's Python thread enqueues ~1.6e4 kernel launches and ~2.6e2
+# graph replays per cycle of 128 captions (bench.py reports `host.enqueue_s_per_cycle`).  Each rank is therefore bound to cores of the
+# NUMA node its GPU hangs off, a disjoint slice per local rank, so that eight enqueue loops neither migrate nor share cores.
+# (The reference harness leaves placement to `accelerate launch`; lmms_eval/evaluator.py:406-411 is one Python loop per rank too.)
+# ---------------------------------------------------------------------------------------------------
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]  (the format of sysfs `local_cpulist`)"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-")
+            out.extend(range(int(lo), int(hi) + 1))
+        else:
+            out.append(int(part))
+    return sorted(set(out))
+
+
+def rank_cpu_slice(local_cpus: Sequence[int], sharers: Sequence[int], me: int, per_rank: int = 0) -> List[int]:
+    """Cores of `local_cpus` for local rank `me` when the local ranks in `sharers` (sorted; `me` among them) hang off the same NUMA
+    node: equal contiguous slices in rank order (at most `per_rank` cores each when > 0), never empty (falls back to all of them)."""
+    cpus, sharers = sorted(local_cpus), sorted(sharers)
+    if not cpus or me not in sharers:
+        return list(cpus)
+    n = len(cpus) // len(sharers)
+    if n < 1:
+        return list(cpus)
+    k = sharers.index(me)
+    sl = cpus[k * n:(k + 1) * n]
+    return sl[:per_rank] if per_rank > 0 else sl
+
+
+def gpu_local_cpus(device_index: int) -> List[int]:
+    """CPUs of the NUMA node GPU `device_index` is attached to (sysfs `local_cpulist` of its PCI function); [] when unknown."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as fh:
+            return parse_cpulist(fh.read())
+    except Exception:                                          # noqa: BLE001 - no sysfs / no GPU: leave the affinity alone
+        return []
+
+
+def pin_rank_to_gpu_numa(local_rank: int, local_world: int, per_rank: int = 0) -> Optional[List[int]]:
+    """Bind this process to its slice of the cores local to its GPU.  Returns the cores, or None if nothing was changed (unknown
+    topology, or a launcher / cgroup already restricted the process to cores outside that node)."""
+    import os
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = gpu_local_cpus(local_rank)
+    if not mine:
+        return None
+    sharers = [r for r in range(local_world) if r == local_rank or gpu_local_cpus(r) == mine]
+    want = set(rank_cpu_slice(mine, sharers, local_rank, per_rank)) & set(os.sched_getaffinity(0))
+    if not want:
+        return None
+    os.sched_setaffinity(0, want)
+    return sorted(want)

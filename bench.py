@@ -120,6 +120,14 @@ def parse():
                         "continuous batching (same work per step, first tokens ~5x later)")
     p.add_argument("--no-latency-point", action="store_true", help="(kept for old command lines; the continuous mode is the default now)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
+    p.add_argument("--tiny-deep", action="store_true", help="host-side rehearsal: tiny widths but the REAL layer counts (31 ViT + 32 Llama layers), so that a cycle "
+                   "enqueues the real number of launches with kernels of a few microseconds - what the host of an 8-rank node has to sustain (`host` in the line)")
+    p.add_argument("--no-single-stream", action="store_true", help="skip the one-slot operating point (`single_stream`: the reference's own use, inference.py:89-96 / "
+                   "EVAL.md 'batch size 1 only'), which the default cfg2 run measures in a child process after the timed steps")
+    p.add_argument("--frontier", action="store_true", help="also measure the (captions/s, p50 TTFT) points of prefill groups 1 / 2 / 8 in child processes (minutes); "
+                   "without it the line's `frontier` holds the three schedules this run times anyway")
+    p.add_argument("--ttft-delay-steps", type=int, default=-1, help="overlapped schedule: the front end of a group starts this many decode steps after the previous "
+                   "boundary instead of at it (-1 = calibrated in the warm-up cycle so that it finishes just before its own boundary: no commit wait)")
     p.add_argument("--config", choices=sorted(CONFIGS), default=None,
                    help="a BASELINE.json config by name (sets --num_frm / --token_kept_ratio / --max_new_tokens / --batch; flags given "
                         "explicitly on the command line still win): " + "; ".join(f"{k} = {v['what']}" for k, v in sorted(CONFIGS.items())))
@@ -313,6 +321,18 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def child_point(flags, timeout=1200):
+    """One more operating point of this benchmark in a child process (its own engine); -> the child's JSON line, or None."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--no-cpu-baseline", "--no-power", "--no-single-stream"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except Exception:                                              # noqa: BLE001 - the parent's line must still print
+        return None
+
+
 def masked_steps_per_chunk(front_ms: float, step_ms: float, chunk_steps: int) -> int:
     """Decode steps of a chunk that run on the decode mask: as many as the front end lasts beside them (both measured in the warm-up
     cycle), at most the chunk's whole steps, at least one."""
@@ -363,13 +383,18 @@ def main():
         if backend == "nccl":
             assert gpus_seen == list(range(world)), f"ranks are not bound one per GPU: {gpus_seen}"
     from aurora_amd import parallel
+    pinned = None
+    if world > 1 and os.environ.get("AURORA_PIN", "1") != "0" and backend == "nccl":
+        pinned = parallel.pin_rank_to_gpu_numa(local, world)       # disjoint NUMA-local core slices: eight enqueue loops share one host
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup, tokens_at_layer, tome_r
 
+    if args.tiny_deep:
+        args.tiny = True
     if args.tiny:
-        cfg = {"vit": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=4, intermediate_size=256, patch_size=14,
+        cfg = {"vit": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=32 if args.tiny_deep else 4, intermediate_size=256, patch_size=14,
                            image_size=112, hidden_act="quick_gelu", layer_norm_eps=1e-5),
-               "llm": dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermediate_size=512, vocab_size=1024,
+               "llm": dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=32 if args.tiny_deep else 2, intermediate_size=512, vocab_size=1024,
                            rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=4.0)}
     else:
         cfg = S.AURORACAP_7B
@@ -471,7 +496,11 @@ def main():
                 eng.decode(min(dc, N - 1 - s0))
                 torch.cuda.current_stream().synchronize()
         else:
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
             eng.decode(N - 1)
+            d1.record()
+            dec_ev.append((d0, d1))
         out = eng.outputs()
         if use_dist and gather:
             parallel.gather_results(out, N, B, cdev)               # RCCL all_gather over xGMI
@@ -483,6 +512,8 @@ def main():
         torch.cuda.synchronize()
 
     out = None
+    dec_ev = []                                                    # (start, end) events around every un-chunked decode of N - 1 steps
+    host_enq = {"enqueue_s": 0.0, "cycles": 0}                     # host seconds spent ENQUEUEING a cycle (before the blocking read-back)
     serving_split = None
     NG, S = (B // G if B % G == 0 else 0), N - 1                   # groups of G slots; decode steps per caption after its prefill
     continuous = not (args.batch_mode or pipe or args.decode_chunk > 0) and NG >= 2 and N >= 2 * NG
@@ -658,6 +689,7 @@ def main():
                 return e0, evf, (front_seq[0], t_host), (ev_v, ev_p)
 
             def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
+                t_enq = time.perf_counter()
                 for g in range(NG):
                     eng.slot_collect(g * G, G, ids_out[g], len_out[g])
                     e0, evf, t_host, (ev_v, ev_p) = pending[0]
@@ -681,8 +713,17 @@ def main():
                     # the commit only, and the decode must never sit behind the host's enqueue time
                     n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
                     k1 = min(n, k_masked) if sDm is not None else 0
+                    # latency-priority order of a chunk (round 5): the steps that run WITHOUT a front end beside them come first, the next
+                    # group's front end starts after them and ends at its own boundary - it used to start at the previous boundary and then
+                    # wait out those steps (`commit_wait`, 34-39 ms of every TTFT).  Same steps, same kernels, same ids.
+                    lead = (n - k1 if args.ttft_delay_steps < 0 else min(args.ttft_delay_steps, n - k1)) if k1 > 0 else 0
+                    go = e1
+                    if lead > 0:
+                        eng.decode(lead)
+                        go = torch.cuda.Event()
+                        go.record(sD)
                     if k1 > 0:
-                        sDm.wait_event(e1)
+                        sDm.wait_event(go)
                         with torch.cuda.stream(sDm):
                             if k_cal["on"]:
                                 evm0 = torch.cuda.Event(enable_timing=True)
@@ -697,12 +738,15 @@ def main():
                             if k_cal["on"]:
                                 k_cal["dec_ev"].append((evm0, evm, k1))
                         sD.wait_event(evm)
-                    if n - k1 > 0:
-                        eng.decode(n - k1)
-                    sF.wait_event(e1)
+                    if n - k1 - lead > 0:
+                        eng.decode(n - k1 - lead)
+                    sF.wait_event(go)
                     pending[0] = front_async((g + 1) % NG)
                     if args.sync_chunks:
                         sD.synchronize()
+                if timed:
+                    host_enq["enqueue_s"] += time.perf_counter() - t_enq
+                    host_enq["cycles"] += 1
                 got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
                 o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
                 if use_dist:
@@ -726,12 +770,14 @@ def main():
             k_cal["dec_ev"].clear()
         sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None
         t_start = time.perf_counter()
+        cpu_start = time.process_time()
         outs = []
         for _ in range(args.steps):
             out = cycle(False, True)
             outs.append(out)
         fence()
         elapsed = time.perf_counter() - t_start
+        host_enq["cpu_s"] = time.process_time() - cpu_start
         power = sampler.stop() if sampler else None
         # same clips in the same slots as the batch-mode step: batch-invariant kernels must give the same ids, every cycle
         assert all(o == batch_ref for o in outs), "continuous batching produced different captions than the batch-mode step"
@@ -893,12 +939,47 @@ def main():
                           "time from the start of a batch's front end to each clip's first token, batch of %d clips (ViT in chunks of %d clips, "
                           "prefill in groups of %d)" % (B, VC, G) + ("; the front end shares the GPU with the previous batch's decode" if pipe else "")),
         }
+        # ---- the host side of a cycle (on an 8-rank node the host is the shared resource)
+        try:
+            aff = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            aff = []
+        result["host"] = {
+            "enqueue_s_per_cycle": (host_enq["enqueue_s"] / host_enq["cycles"]) if host_enq["cycles"] else None,
+            "enqueue_frac_of_cycle": (host_enq["enqueue_s"] / host_enq["cycles"] / (elapsed / args.steps)) if host_enq["cycles"] else None,
+            "process_cpu_s_per_cycle": (host_enq["cpu_s"] / args.steps) if "cpu_s" in host_enq else None,
+            "process_cpu_util": (host_enq["cpu_s"] / elapsed) if "cpu_s" in host_enq else None,
+            "cores_allowed": len(aff), "pinned_to_gpu_numa_cores": pinned,
+            "note": "enqueue = host wall time of the Python thread that issues a cycle's launches, up to (not including) the blocking read-back of "
+                    "the ids; process_cpu = user + system seconds of the whole process (enqueue thread, the two TTFT helper threads, the power sampler) "
+                    "per cycle.  Ranks of a multi-GPU job are bound to disjoint slices of their GPU's NUMA-local cores (aurora_amd.parallel.pin_rank_to_gpu_numa)"}
+        if dec_ev:
+            dms = float(np.median([a.elapsed_time(b) for a, b in dec_ev]))
+            d_, mlp_ = l["hidden_size"], l["intermediate_size"]
+            wb = 2.0 * (l["num_hidden_layers"] * (4 * d_ * d_ + 3 * d_ * mlp_) + l["vocab_size"] * d_)
+            kvb = B * 2.0 * l["num_hidden_layers"] * d_ * 2 * (L0 + N / 2.0)
+            result["decode_step"] = {"bound": "hbm", "slots": B, "ms_per_step": dms / (N - 1), "tokens_per_s": B * (N - 1) / (dms * 1e-3),
+                                     "ideal_ms_per_step": 1e3 * (wb + kvb) / 8e12, "frac": (1e3 * (wb + kvb) / 8e12) / (dms / (N - 1)),
+                                     "ideal_tokens_per_s": B * 8e12 / (wb + kvb), "weight_bytes_per_step": wb, "kv_bytes_per_step_mean": kvb,
+                                     "how": "device events around the %d hipGraph replays of one generation on %d slots, nothing else on the GPU "
+                                            "(median of %d); ideal = weights once + K / V of every cached token at 8 TB/s (SURVEY 8d)" % (N - 1, B, len(dec_ev))}
         if continuous and overlap:
             result["sequential_schedule"] = seq_sched
         if continuous:
             result["batch_mode"] = {"captions_per_s": B / (batch_ms / 1e3), "ms_per_step": batch_ms, "p50_ttft_ms": batch_ttft,
                                     "note": "one step of the non-continuous schedule (all %d front ends, then the %d-wide decode), same captions; "
                                             "host-timed around a single step after warm kernels" % (B, B)}
+
+    if rank == 0:
+        pts = [{"schedule": "this run (`value`)", "prefill_group": G, "overlap": bool(continuous and overlap), "captions_per_s": result["value"],
+                "p50_ttft_ms": result["p50_ttft_ms"]}]
+        if continuous and overlap and seq_sched:
+            pts.append({"schedule": "sequential (front ends between decode chunks)", "prefill_group": G, "overlap": False,
+                        "captions_per_s": seq_sched["captions_per_s"], "p50_ttft_ms": seq_sched["p50_ttft_ms"]})
+        if continuous:
+            pts.append({"schedule": "batch mode (all front ends, then the decode)", "prefill_group": G, "overlap": False,
+                        "captions_per_s": B / (batch_ms / 1e3), "p50_ttft_ms": batch_ttft})
+        result["frontier"] = pts
 
     # ---- instrumented pass (rank 0, after the timed region, not pipelined): HIP events per stage and around the
     #      two HBM-bound decode kernels
@@ -909,6 +990,7 @@ def main():
         front(0)
         back(0, gather=False)
         stages = {k: eng.profile_read(k)[0] for k in ("vit", "project", "prefill", "decode")}
+        tome_ms_batch, tome_n_batch = eng.profile_read("vit_tome")
         ams, an = eng.profile_read("decode_attn")
         kms, kn = eng.profile_read("decode_gemm_gateup")
         eng.profile(False)
@@ -920,7 +1002,7 @@ def main():
         pmc, pmc_ctx, pmc_tag, pmc_build = {}, None, "r02", None
         try:
             pj = None
-            for tag in ("r04", "r03", "r02"):                          # the newest committed counter summary
+            for tag in ("r05", "r04", "r03", "r02"):                   # the newest committed counter summary
                 fp = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
                 if os.path.exists(fp):
                     pj, pmc_tag = json.load(open(fp)), tag
@@ -1046,11 +1128,37 @@ def main():
         torch.cuda.synchronize()
         st1 = {k: eng.profile_read(k)[0] for k in ("vit", "vit_tome", "project", "prefill", "first_token")}
         eng.profile(False)
+        # ---- token merge against its HBM bound (north_star: "evidenced by rocprof HBM GB/s"; SURVEY 8d bytes per frame-layer =
+        #      2 (t c + t D + (t - r) D) + 4 (2 t - r): the metric, the state read and the merged state written, the index arrays)
+        if not args.tiny:
+            hdv_ = v["hidden_size"] // v["num_attention_heads"]
+            tb_, tt_ = 0.0, t0tok
+            for _ in range(v["num_hidden_layers"] - 1):
+                rl_ = min(r, (tt_ - 1) // 2)
+                if rl_ > 0:
+                    tb_ += 2.0 * (tt_ * hdv_ + tt_ * v["hidden_size"] + (tt_ - rl_) * v["hidden_size"]) + 4.0 * (2 * tt_ - rl_)
+                tt_ -= rl_
+            tome_bytes_clip = F * tb_
+            tome_pmc = [pmc_of(k) for k in ("tome_prep_kernel", "tome_match_kernel", "tome_select_kernel", "tome_merge_kernel")]
+            tome_traffic = sum(e["hbm_bytes_per_launch"] for e in tome_pmc) if all(tome_pmc) else None
+            sv_clips = min(VC, B)
+            result["roofline_tome"] = {
+                "bound": "hbm", "kernel": "tome_prep / tome_match (v_mfma_f32_16x16x4_f32) / tome_select / tome_merge (+ LayerNorm 2), four launches per layer",
+                "achieved": (B * tome_bytes_clip / (tome_ms_batch * 1e-3) / 1e9) if tome_ms_batch > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                "frac": (B * tome_bytes_clip / (tome_ms_batch * 1e-3) / 8e12) if tome_ms_batch > 0 else None,
+                "traffic": tome_traffic, "traffic_note": "sum of the four launches' (2*FETCH_SIZE + WRITE_SIZE) KiB per layer-launch in profiles/%s_pmc.json, at %d "
+                                                         "frames per launch; null until a counter pass of this build is committed" % (pmc_tag, G * F),
+                "algorithmic_bytes_per_clip": tome_bytes_clip, "algorithmic_bytes_per_layer_launch_mean": sv_clips * tome_bytes_clip / max(v["num_hidden_layers"] - 1, 1),
+                "ms_per_clip": (tome_ms_batch / B) if tome_ms_batch > 0 else None, "frames_per_launch": sv_clips * F,
+                "single_clip": {"ms": st1["vit_tome"], "achieved": tome_bytes_clip / (st1["vit_tome"] * 1e-3) / 1e9 if st1["vit_tome"] > 0 else None,
+                                "frac": tome_bytes_clip / (st1["vit_tome"] * 1e-3) / 8e12 if st1["vit_tome"] > 0 else None, "frames_per_launch": F},
+                "how": "HIP events around the ToMe launches of every layer (aur_profile 'vit_tome') in the instrumented eager step (%d clips per ViT pass) and in "
+                       "one single-clip pass; the merge launch also writes LayerNorm 2's output (not counted in the algorithmic bytes)" % sv_clips}
         result["ttft_stage_ms"] = {
             "single_clip": {"vit_without_tome": st1["vit"] - st1["vit_tome"], "tome": st1["vit_tome"], "projector_splice": st1["project"],
                             "prefill_layers": st1["prefill"] - st1["first_token"], "lm_head_argmax": st1["first_token"],
                             "sum": st1["vit"] + st1["project"] + st1["prefill"],
-                            "note": "one clip alone on the whole GPU, stage timers (HIP events) of one extra pass; ToMe = the three launches per layer"},
+                            "note": "one clip alone on the whole GPU, stage timers (HIP events) of one extra pass; ToMe = the four launches per layer (the last one also writes LayerNorm 2)"},
             "serving": serving_split}
         hl = []
         for _ in range(3):                                            # the same, on the host clock, including the read-back of the slot state
@@ -1068,6 +1176,27 @@ def main():
     eng.close()
     del eng
     torch.cuda.empty_cache()
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
+    if rank == 0 and world == 1 and not args.tiny and not profiled and args.config_name == "cfg2" and B > 1:
+        # ---- operating points measured in child processes (each builds its own engine: the kernel structure is a constant of the engine)
+        if not args.no_single_stream:
+            # the reference's own use: one clip at a time (inference.py:89-96; docs/auroracap/EVAL.md:61 "batch size 1 only")
+            c = child_point(["--batch", "1", "--steps", "2", "--warmup", "1", "--no-instrument"])
+            ds = (c or {}).get("decode_step") or {}
+            result["single_stream"] = ({"error": "the child run produced no line"} if not c or "value" not in c else {
+                "captions_per_s": c["value"], "ms_per_caption": c["ms_per_step"], "p50_ttft_ms": c["p50_ttft_ms"],
+                "decode_tokens_per_s": ds.get("tokens_per_s"), "decode_ms_per_step": ds.get("ms_per_step"),
+                "ideal_tokens_per_s": ds.get("ideal_tokens_per_s"), "frac": ds.get("frac"), "bound": "hbm",
+                "how": "`python bench.py --batch 1` in a child process (one KV slot, hipGraph decode, 2 timed captions); frac = (13.21 GB of weights + "
+                       "K / V of the mean context) / 8 TB/s over the measured decode step"})
+        if args.frontier:
+            for g_ in (1, 2, 8):
+                if g_ == G:
+                    continue
+                c = child_point(["--prefill-group", str(g_), "--steps", "1", "--warmup", "1", "--no-instrument"])
+                if c and "value" in c:
+                    result["frontier"].append({"schedule": "default schedule, groups of %d (child process, 1 timed cycle)" % g_, "prefill_group": g_,
+                                               "overlap": True, "captions_per_s": c["value"], "p50_ttft_ms": c["p50_ttft_ms"]})
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         try:
             result["cpu_baseline"] = cpu_baseline(cfg, args, n_kept)

@@ -1,0 +1,29 @@
+"""Frozen floating-point bounds of the -m gpu suite (SURVEY 8c parity contract (ii)-(iv): "calibrate on first GPU run and then freeze").
+
+Every bound here was set from profiles/r05_parity_observed.json - the worst value each comparison showed on MI355X, recorded by
+tests.util.observe() - at no more than 3x that value (counts: the observed count minus one).  tests/test_parity_bounds.py (CPU)
+checks exactly that against the committed file, so a bound cannot drift loose again without the record saying so.
+Rounds 1-4 ran on 3e-2 / 5e-3 / "agree >= total - 3" / "rate >= 0.5": 10-40x looser than anything the kernels ever showed.
+"""
+# logits vs the fp32 oracle, max-abs relative to max |logit| (teacher-forced), small model configs; also the half-width of the
+# margin rule (tokens must equal the oracle's wherever its top-1 / top-2 margin exceeds twice this).  Observed worst: 7.3e-4
+LOGIT_TOL = 2e-3
+# the same at Llama-7B WIDTH (4096 / 11008 / 32000) and 2 layers over a 300-row prefix: longer dot products.  Observed 1.23e-3
+LOGIT_TOL_WIDE = 3.5e-3
+# the same at Llama-7B width AND depth (32 layers: 64 fp16 roundings of the residual stream, each 2^-11 relative).  Observed 8.3e-3
+LOGIT_TOL_DEEP = 2.5e-2
+# hidden states / features vs the fp32 oracle on identical merges, rel-L2.  Observed worst 6.5e-4 (G7 erf-GELU chain, free running)
+FEAT_TOL = 1.9e-3
+# two decode-attention kernels of different summation order against each other, relative to max |logit|.  Observed 4.3e-4
+VARIANT_TOL = 1.2e-3
+# the two decode-projection structures (x per wave / x through LDS) against each other.  Observed 2.0e-4
+STRUCTURE_TOL = 6e-4
+# an index difference against the fp32 oracle / the reference-held arrays must be a near tie of the fp32 scores: largest gap
+# accepted.  Observed worst 1.2e-4 (G7 mid, r boundary), 3.9e-5 (ViT-H free run)
+NEAR_TIE = 3.6e-4
+# G7 mid encoder: frame-layers (of 16) on which the reference's own index arrays are reproduced exactly.  Observed 13
+G7_MID_AGREE = 12
+# ViT-H free run against the oracle's own free run: frame-layers with identical indices before each frame's first flip.  Observed 15
+FREE_RUN_AGREE = 14
+# ... and the mean-feature drift once the token sets have diverged at a near tie.  Observed 2.4e-2
+FREE_RUN_DRIFT = 7e-2

@@ -11,7 +11,8 @@ import torch
 
 from oracle import aurora_oracle as O
 from oracle import tome_ref
-from tests.util import rand_llm_weights, rand_vit_weights, rel_l2, to_match
+from tests.parity_bounds import FEAT_TOL, FREE_RUN_AGREE, FREE_RUN_DRIFT, LOGIT_TOL_DEEP, LOGIT_TOL_WIDE, NEAR_TIE
+from tests.util import observe, rand_llm_weights, rand_vit_weights, rel_l2, to_match
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +45,7 @@ def test_vit_h_width_layers_teacher_forced(ratio, frames):
             for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
                 np.testing.assert_array_equal(idx[k].cpu().numpy(), mc[k], err_msg=f"layer {layer} {k}")
             xr, sr = O.vit_layer(x, size, w["layers"][layer], 16, r, "quick_gelu", forced_match=to_match(idx))
-            assert rel_l2(xo.float().cpu(), xr) < 5e-3
+            observe("configs/vit_h_single_layer_rel_l2", rel_l2(xo.float().cpu(), xr), FEAT_TOL)
             assert xo.shape[1] == x.shape[1] - r
             x, size = xo.float().cpu(), so.cpu()[..., None]
     finally:
@@ -71,15 +72,24 @@ def test_llama_7b_width_prefill_and_decode_logits():
         ref = teacher_forced_logits(emb, ids, w, cfg)
         scale = ref.abs().max().item()
         for i in range(6):
-            assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, i
+            observe("configs/llama7b_width_2_layers_logits_over_scale", (logits[i] - ref[i]).abs().max().item() / scale, LOGIT_TOL_WIDE)
         # cfg2 prefix length (2142): batched prefill == per-slot prefill, graph decode deterministic
         g = torch.Generator().manual_seed(2)
         embs = [(torch.randn(2142, 4096, generator=g) * 0.5).half() for _ in range(3)]
         big = torch.cat([padded(e.float()) for e in embs], 0).contiguous()
         eng.begin_batch(3, 16, None)
         eng.prefill_batch(0, 3, big, 2142)
+        first = eng.logits()[:3].cpu()                              # logits of the LAST prompt position of every sequence
         eng.decode(15)
         a = eng.outputs()
+        # the 2142-row prefill (cfg2's prefix length: 67 query blocks, 34 pages) had only ever met bitwise
+        # properties.  One sequence through the fp32 oracle at this width: its last-position logits are the first token's
+        h, _ = O.llama_forward(embs[0].float(), w, cfg, None, 0)
+        ref_first = torch.nn.functional.linear(h[-1:], w["lm_head.weight"])[0]
+        observe("configs/llama7b_width_2142_row_prefill_first_token_logits_over_scale",
+                (first[0] - ref_first).abs().max().item() / ref_first.abs().max().item(), LOGIT_TOL_WIDE)
+        if (ref_first.topk(2).values[0] - ref_first.topk(2).values[1]).item() > 2 * LOGIT_TOL_WIDE * ref_first.abs().max().item():
+            assert a[0][0] == int(ref_first.argmax())
         eng.begin_batch(3, 16, None)
         for b in range(3):
             eng.prefill(b, padded(embs[b].float()), 2142)
@@ -119,7 +129,7 @@ def test_long_kv_decode_many_pages_cfg5_shape():
     full = torch.cat([emb, w["embed_tokens.weight"][torch.tensor(ids[:-1], dtype=torch.long)]], 0)
     h, _ = O.llama_forward(full, w, cfg, None, 0)
     ref_last = torch.nn.functional.linear(h[-1:], w["lm_head.weight"])[0]
-    assert (last_logits - ref_last).abs().max().item() <= LOGIT_TOL * ref_last.abs().max().item()
+    observe("configs/cfg5_shape_last_logits_over_scale", (last_logits - ref_last).abs().max().item() / ref_last.abs().max().item(), LOGIT_TOL)
     # every generated token is the first argmax of logits that agree with the oracle wherever its margin is clear
     ref_all = torch.nn.functional.linear(h[L0 - 1:], w["lm_head.weight"])
     top2 = ref_all.topk(2, dim=-1).values
@@ -186,7 +196,7 @@ def test_vit_h_full_depth_every_layer_teacher_forced(norm_std, bias_std):
             xr, _ = O.vit_layer(x, size, w["layers"][layer], v["num_attention_heads"], r, v["hidden_act"], forced_match=to_match(idx))
             err = rel_l2(xo.float().cpu(), xr)
             worst = max(worst, err)
-            assert err < 5e-3, (layer, err)
+            observe("configs/vit_h_every_layer_teacher_forced_rel_l2", err, FEAT_TOL)
             assert xo.shape[1] == x.shape[1] - r
             x, size = xo.float().cpu(), so.cpu()[..., None]
         assert x.shape[1] == 265                                                  # 264 patch tokens + CLS enter layer 31
@@ -225,7 +235,7 @@ def test_llama_7b_full_depth_teacher_forced_logits(norm_std):
     ref = teacher_forced_logits(emb, ids, w, cfg)
     scale = ref.abs().max().item()
     for i in range(6):
-        assert (logits[i] - ref[i]).abs().max().item() <= LOGIT_TOL * scale, (i, (logits[i] - ref[i]).abs().max().item(), scale)
+        observe("configs/llama7b_full_depth_logits_over_scale", (logits[i] - ref[i]).abs().max().item() / scale, LOGIT_TOL_DEEP)
 
 
 def test_projector_and_splice_at_real_size():
@@ -242,7 +252,7 @@ def test_projector_and_splice_at_real_size():
         ref = O.splice(torch.tensor(ids), w["llm"]["embed_tokens.weight"],
                        O.projector(vis.float().reshape(1, -1, 1280), w["projector"]).reshape(8, 264, -1))
         assert L == ref.shape[0] == 30 + 8 * 264
-        assert rel_l2(emb[:L].float().cpu(), ref) < 5e-3
+        observe("configs/project_splice_real_size_rel_l2", rel_l2(emb[:L].float().cpu(), ref), FEAT_TOL)
         text_rows = [i for i, t in enumerate(ids) if t != -200]
         row = 0
         for t in ids:                                               # text rows are exact copies of the embedding table
@@ -318,7 +328,7 @@ def test_vit_h_free_running_index_audit():
                         if pos_o[a] != i:
                             worst = max(worst, abs(nmax[a].item() - nmax[o_src[i]].item()))
                 flips.append((layer, f, worst))
-                assert worst < 2e-3, f"layer {layer} frame {f}: index difference that is not a near tie of the fp32 scores ({worst})"
+                observe("configs/vit_h_free_run_flip_score_gap", worst, NEAR_TIE)        # an index difference must be a near tie of the fp32 scores
             x, size = xo.float().cpu(), so.cpu()[..., None]
         rate = agree / max(compared, 1)
         feats = x[:, 1:]
@@ -327,11 +337,12 @@ def test_vit_h_free_running_index_audit():
         print(f"\nViT-H free run: indices agree on {agree} of {compared} comparable frame-layers ({100 * rate:.1f} %); first flips (layer, frame, "
               f"score gap): {[(l, f, round(g, 6)) for l, f, g in flips]}; frames still identical at layer {L}: {sum(alive)} of {F}; "
               f"final feature rel-L2 {drift:.4f}, mean-feature rel-L2 {mean_drift:.4f}")
-        assert compared >= F and rate >= 0.5, (agree, compared)
+        assert compared >= F
+        observe("configs/vit_h_free_run_agreeing_frame_layers", agree, FREE_RUN_AGREE, at_least=True)
         assert feats.shape == feats_ref.shape
-        assert mean_drift < 0.15, mean_drift                   # ~6.5 % once a near tie has flipped; identical chains give < 5e-3
+        observe("configs/vit_h_free_run_mean_feature_drift", mean_drift, FREE_RUN_DRIFT)   # once a near tie has flipped the token sets differ; identical chains give < FEAT_TOL
         if all(alive):
-            assert drift < 5e-3, drift
+            observe("configs/vit_h_free_run_identical_chain_rel_l2", drift, FEAT_TOL)
     finally:
         eng.close()
 

@@ -20,7 +20,8 @@ import torch
 
 from oracle import aurora_oracle as O
 from tests.test_oracle_golden import mid_encoder_weights
-from tests.util import cfg_of, enc_layers, golden, rel_l2, sub, tt
+from tests.util import cfg_of, enc_layers, golden, observe, rel_l2, sub, tt
+from tests.parity_bounds import FEAT_TOL, G7_MID_AGREE, NEAR_TIE
 
 pytestmark = pytest.mark.gpu
 
@@ -55,9 +56,9 @@ def test_g7_encoder_chain_layer_by_layer(tag):
             xo, so, _, idx = eng.vit_layer(li, x, size, cfg["r"])
             want = held.get(li + 1, ref[li + 1])
             assert xo.shape == want.shape, (li, xo.shape, want.shape)
-            assert rel_l2(xo.float().cpu(), want) < 5e-3, (tag, li, rel_l2(xo.float().cpu(), want))
+            observe(f"golden/g7_{tag}_layer_rel_l2", rel_l2(xo.float().cpu(), want), FEAT_TOL)
             x, size = xo.float().cpu(), so.cpu()[..., None]           # free running: the GPU's own state feeds the next layer
-        assert rel_l2(x, held[cfg["L"]]) < 5e-3
+        observe(f"golden/g7_{tag}_final_rel_l2", rel_l2(x, held[cfg["L"]]), FEAT_TOL)
     finally:
         eng.close()
 
@@ -84,7 +85,7 @@ def test_g7_mid_encoder_reference_indices_and_rows_hd80():
                     agree += 1
                     got = xo[f].float().cpu()[rows]
                     want = tt(g[f"hs{li + 1}_rows"])[f]
-                    assert rel_l2(got, want) < 5e-3, (li, f, rel_l2(got, want))
+                    observe("golden/g7_mid_rows_rel_l2", rel_l2(got, want), FEAT_TOL)
                 else:
                     # audit: the GPU evaluates the metric from fp16 K, the reference in fp32; a different choice must be a near tie
                     m = cap[li]["metric"][f]
@@ -96,12 +97,13 @@ def test_g7_mid_encoder_reference_indices_and_rows_hd80():
                     boundary = nmax[order[cfg["r"] - 1]].item()
                     gs, rs = set(idx["src_idx"][f].tolist()), set(g[f"l{li}_src_idx"][f].tolist())
                     for a in gs ^ rs:
-                        assert abs(nmax[a].item() - boundary) < 2e-3, (li, f, a, nmax[a].item(), boundary)
+                        observe("golden/g7_mid_flip_boundary_gap", abs(nmax[a].item() - boundary), NEAR_TIE)
                     top2 = sc.topk(2, dim=-1).values
                     for k, a in enumerate(g[f"l{li}_src_idx"][f].tolist()):
                         if a in gs and int(idx["dst_idx"][f][idx["src_idx"][f].tolist().index(a)]) != int(g[f"l{li}_dst_idx"][f][k]):
-                            assert (top2[a, 0] - top2[a, 1]).item() < 2e-3, (li, f, a)
-        assert agree >= total - 3, f"reference indices reproduced on {agree} of {total} frame-layers"
+                            observe("golden/g7_mid_flip_top2_gap", (top2[a, 0] - top2[a, 1]).item(), NEAR_TIE)
+        print(f"\nG7 mid: reference indices reproduced on {agree} of {total} frame-layers")
+        observe("golden/g7_mid_frame_layers_with_reference_indices", agree, G7_MID_AGREE, at_least=True)
     finally:
         eng.close()
 

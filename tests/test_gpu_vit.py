@@ -10,7 +10,8 @@ import torch
 
 from oracle import aurora_oracle as O
 from oracle import tome_ref
-from tests.util import rand_vit_weights, rel_l2, to_match
+from tests.parity_bounds import FEAT_TOL
+from tests.util import observe, rand_vit_weights, rel_l2, to_match
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +55,7 @@ def test_vit_layer_teacher_forced(name):
             xr, sr = O.vit_layer(x, size, w["layers"][layer], heads, r, cfg["hidden_act"], forced_match=to_match(idx), capture=cap)
             np.testing.assert_allclose(metric.cpu().numpy(), cap[0]["metric"].numpy(), rtol=5e-3, atol=5e-3)
             # (iii) features with forced (= GPU) merges
-            assert rel_l2(xo.float().cpu(), xr) < 5e-3, f"layer {layer}"
+            observe(f"vit/layer_teacher_forced_rel_l2[{name}]", rel_l2(xo.float().cpu(), xr), FEAT_TOL)
             np.testing.assert_array_equal(so.cpu().numpy(), sr[..., 0].numpy())
             # agreement of the fp32 oracle's own src set with the GPU's (near-tie audit)
             own = O.bipartite_match(cap[0]["metric"], r)
@@ -83,7 +84,7 @@ def test_vit_encode_end_to_end(name):
         out = eng.vit_encode(px, rr).float().cpu()
         ref = O.vit_features(px, w, cfg, ratio, q=O.fp16_storage)
         assert out.shape == ref.shape
-        assert rel_l2(out.mean(1), ref.mean(1)) < 1e-2
+        observe(f"vit/encode_end_to_end_mean_feature_rel_l2[{name}]", rel_l2(out.mean(1), ref.mean(1)), 1e-2)
         if rel_l2(out, ref) > 1e-2:          # merges diverged at a near-tie: rows are permuted, compare sorted norms
             assert rel_l2(out.norm(dim=-1).sort(-1).values, ref.norm(dim=-1).sort(-1).values) < 2e-2
     finally:
@@ -100,7 +101,7 @@ def test_vit_encode_ratio_one_exact_schedule():
         out = eng.vit_encode(px, eng.tome_r(1.0)).float().cpu()
         ref = O.vit_features(px, w, cfg, 1.0)
         assert out.shape == (frames, 16, 64)
-        assert rel_l2(out, ref) < 5e-3
+        observe("vit/encode_ratio_one_rel_l2", rel_l2(out, ref), FEAT_TOL)
     finally:
         eng.close()
 
@@ -136,4 +137,33 @@ def test_vit_layer_gemm256_equals_gemm128(name):
         assert torch.equal(outs[0][0], outs[1][0])
     finally:
         eng.set_option("gemm_mode", 1)
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_hd16", "hd80_gelu", "mid_t730"])
+def test_layernorm2_out_of_the_merge_launch_is_bitwise_the_separate_launch(name):
+    """Round 5: a merging layer's LayerNorm 2 (aurora.py:750) is written by the ToMe select + merge launch from the registers that hold
+    the merged row (tome.hip), instead of a norm_kernel pass that reads it back.  Same operations in the same order on the rounded fp16
+    row: every layer output (and with it the size vector and the indices) must be BITWISE that of the two-launch form
+    (`tome_fused_ln` 0), with and without a carried size vector, pad rows included (they feed the next GEMM's tiles)."""
+    cfg, frames, r = CFGS[name]
+    eng, _ = make_engine(cfg, frames, 11)
+    try:
+        t = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+        gen = torch.Generator().manual_seed(3)
+        x = torch.randn(frames, t, cfg["hidden_size"], generator=gen).half().float()
+        size = None
+        for layer in range(cfg["num_hidden_layers"] - 1):
+            outs = []
+            for fused in (1, 0, 1):
+                eng.set_option("tome_fused_ln", fused)
+                xo, so, metric, idx = eng.vit_layer(layer, x, size, r)
+                outs.append((xo.cpu(), so.cpu(), {k: v.cpu() for k, v in idx.items() if hasattr(v, "cpu")}))
+            for other in outs[1:]:
+                assert torch.equal(outs[0][0], other[0]) and torch.equal(outs[0][1], other[1]), (name, layer)
+                for k in ("node_idx", "unm_idx", "src_idx", "dst_idx"):
+                    assert torch.equal(outs[0][2][k], other[2][k]), (name, layer, k)
+            x, size = outs[0][0].float(), outs[0][1][..., None]
+    finally:
+        eng.set_option("tome_fused_ln", 1)
         eng.close()

