@@ -85,7 +85,9 @@ def projector_config(d: str) -> dict:
     class defaults.  `ProjectorModel.__init__` (modeling_projector.py:20-33) builds `depth` Linear layers with `ACT2FN[hidden_act]`
     between them and an optional bias - all three are honoured by the engine or rejected loudly (aurora_amd.engine.projector_settings)."""
     p = os.path.join(d, "config.json")
-    c = _json(p) if os.path.exists(p) else {}
+    if not os.path.exists(p):      # the reference's ProjectorModel.from_pretrained needs it too; the class defaults (4096 -> 4096) fit no AuroraCap
+        raise FileNotFoundError(f"{p} not found: the projector sub-directory of an xtuner-format checkpoint holds config.json beside its weights")
+    c = _json(p)
     return dict(visual_hidden_size=c.get("visual_hidden_size", 4096), llm_hidden_size=c.get("llm_hidden_size", 4096),
                 depth=c.get("depth", 2), hidden_act=c.get("hidden_act", "gelu"), bias=c.get("bias", True))
 

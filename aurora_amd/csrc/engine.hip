@@ -37,6 +37,8 @@ struct StageTimer {
     double ms = 0;
     int64_t launches = 0;
     bool open = false;
+    uint64_t range_id = 0;       // roctx range of the stage (AURORA_ROCTX=1)
+    bool range_open = false;
 };
 
 struct aur_ctx {
@@ -485,18 +487,21 @@ extern "C" int aur_pack_linear(aur_ctx* ctx, const void* w, int32_t n_src, int32
 // its name instead of by kernel name only.  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so)
 // when AURORA_ROCTX=1 is set - the product library has no link-time dependency on a profiler, and without the variable a range costs one
 // predictable branch.  Ranges bracket the host-side ENQUEUE of a stage (what roctx measures); the device time is in the kernel trace.
+// Ranges are START / STOP ranges with ids (not the push / pop stack): an entry point that fails between stage_begin and stage_end
+// (every CK() is an early return) leaves ONE unclosed range, which the next stage_begin of that name closes - the nesting of later
+// stages cannot be skewed.
 struct Roctx {
-    int (*push)(const char*) = nullptr;
-    int (*pop)() = nullptr;
+    uint64_t (*start)(const char*) = nullptr;
+    void (*stop)(uint64_t) = nullptr;
     Roctx() {
         const char* on = getenv("AURORA_ROCTX");
         if (!on || on[0] != '1') return;
         void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return;
-        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
-        pop = (int (*)())dlsym(h, "roctxRangePop");
-        if (!push || !pop) push = nullptr, pop = nullptr;
+        start = (uint64_t (*)(const char*))dlsym(h, "roctxRangeStartA");
+        stop = (void (*)(uint64_t))dlsym(h, "roctxRangeStop");
+        if (!start || !stop) start = nullptr, stop = nullptr;
     }
 };
 static const Roctx& roctx() {
@@ -504,7 +509,12 @@ static const Roctx& roctx() {
     return r;
 }
 static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
-    if (roctx().push) roctx().push(name);
+    if (roctx().start) {
+        StageTimer& tr = c->timers[name];
+        if (tr.range_open) roctx().stop(tr.range_id);       // left open by a call that failed mid-stage
+        tr.range_id = roctx().start(name);
+        tr.range_open = true;
+    }
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
     if (!t.e0) {
@@ -521,7 +531,11 @@ static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
     (void)hipEventRecord(t.e0, s);
 }
 static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
-    if (roctx().pop) roctx().pop();
+    if (roctx().stop) {
+        StageTimer& tr = c->timers[name];
+        if (tr.range_open) roctx().stop(tr.range_id);
+        tr.range_open = false;
+    }
     if (!c->prof) return;
     StageTimer& t = c->timers[name];
     (void)hipEventRecord(t.e1, s);
@@ -1052,10 +1066,9 @@ static int prefill_first_tokens(aur_ctx* ctx, int slot0, int nseq, void* embeds,
     if (ctx->prof) kev_begin(ctx->kev[3], s);
     CK(launch_xfrag_norm((half_t*)embeds + (int64_t)(seq_len - 1) * d, (int64_t)Mseq * d, nullptr, g.llm_rms_eps, nseq, d, slot0, ctx->d_x, ctx->s_ssq_mlp, s));
     int rc = lm_head_and_advance(ctx, slot0, nseq, 0, seq_len, s);
-    if (rc) return rc;
-    if (ctx->prof) kev_end(ctx->kev[3], s);
+    if (ctx->prof) kev_end(ctx->kev[3], s);       // closed on the error path too: the event ring and the roctx nesting stay balanced
     stage_end(ctx, stage, s);
-    return AUR_OK;
+    return rc;
 }
 
 extern "C" int aur_llm_prefill_batch(aur_ctx* ctx, int32_t slot0, int32_t nseq, void* embeds, int32_t seq_len, void* stream) {
@@ -1315,8 +1328,8 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
     } else if (!strcmp(name, "dec_attn_fused_combine")) {
-        // 1 (default): with several splits per (sequence, head) the split that arrives last combines the partials inside the attention
-        // kernel (decode.hip); 0: decode_attn_combine_kernel does, in a second launch.  Bitwise the same output.
+        // 0 (default): decode_attn_combine_kernel combines the splits of a (sequence, head) in a second launch; 1: the split that arrives
+        // last combines them inside the attention kernel (decode.hip).  Bitwise the same output.
         ctx->attn_fused_combine = value ? 1 : 0;
     } else if (!strcmp(name, "decode_fused_reduce")) {
         // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (the last-arriving split reduces;

@@ -146,7 +146,9 @@ static hipError_t launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     // the QKV epilogue treats a 16-row block as 16 consecutive tokens of one sequence, one page and one fragment row (gemm_epilogue.h)
-    if (epi == EPI_QKV && (((a.M | a.rows_per_seq | a.pos0 | a.kv.page_tokens) & 15) != 0 || a.M % a.rows_per_seq != 0)) return hipErrorInvalidValue;
+    // EPI_QKV: every 16-row block is 16 consecutive tokens of one sequence, page and fragment row; the V third pairs two of them
+    if (epi == EPI_QKV && (a.rows_per_seq <= 0 || ((a.M | a.rows_per_seq | a.pos0 | a.kv.page_tokens) & 15) != 0 || (a.rows_per_seq & 31) != 0 ||
+                           a.M % a.rows_per_seq != 0)) return hipErrorInvalidValue;
     if (!((a.gemm_mode == 1 && gemm256_eligible(a)) || (a.gemm_mode == 2 && (a.Npad & 255) == 0))) return launch_gemm128(a, epi, s);
     // Tile quantisation: the persistent 256x256 kernel runs ceil(tiles / G) rounds of G workgroups, and a GEMM of few rounds can
     // leave most of the last one idle (o / down projection of a 4-clip prefill pass: 544 tiles = 4.25 rounds of 128, 2.1 of 256).

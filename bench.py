@@ -104,8 +104,8 @@ def parse():
     p.add_argument("--gemm-nt-out", type=int, default=-1, help="A/B: GEMM output stores 0 = default cache policy, 1 = non-temporal, -1 (engine default) = non-temporal "
                    "for outputs larger than the L2s together")
     p.add_argument("--dec-attn-pps", type=int, default=0, help="A/B: KV pages per decode-attention split (0 = the engine's choice: ~512 waves on the GPU)")
-    p.add_argument("--attn-fused-combine", type=int, default=-1, help="A/B: 1 (engine default) = the last-arriving split of the VALU decode attention combines "
-                   "the partials in the kernel, 0 = decode_attn_combine_kernel follows as its own launch")
+    p.add_argument("--attn-fused-combine", type=int, default=-1, help="A/B: 0 (engine default) = decode_attn_combine_kernel follows the VALU decode attention as its own "
+                   "launch, 1 = the last-arriving split combines the partials in the kernel")
     p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
                                                             "launches short - rocprofv3's counter mode crashed with ~11 k launches queued ahead of the GPU)")
     p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "

@@ -121,7 +121,11 @@ int aur_vit_encode_hw(aur_ctx* ctx, const void* pixels, int32_t frames, int32_t 
  * prepare_inputs_labels_for_multimodal (model/utils.py:138-295) for one sequence.
  * vis: fp16 [nvis, vit_hidden]; vis_rows / text_rows: device int32 destination rows in `embeds`
  * (row order of the spliced sequence, computed on the host from input_ids); text_ids: device int32.
- * embeds: fp16 [rows_pad, llm_hidden] with rows_pad = round_up(seq_len, 32) (pad rows zeroed here). */
+ * embeds: fp16 [rows_pad, llm_hidden] with rows_pad = round_up(seq_len, 32) (pad rows zeroed here).
+ * STREAM RULE: the projector's intermediates live in the ctx's front-end scratch (the prefill layers' normalised-input and MLP
+ * buffers: a projector of depth >= 3 ping-pongs through both), so a splice must be ordered against every aur_llm_prefill* /
+ * aur_llm_prefill_stage call of the same ctx - enqueue them on ONE stream (as aurora_amd.engine does) or order the streams
+ * with events; a splice on another stream beside a running prefill corrupts that prefill silently. */
 int aur_project_splice(aur_ctx* ctx, const void* vis, int32_t nvis, const int32_t* vis_rows,
                        const int32_t* text_ids, const int32_t* text_rows, int32_t ntext,
                        int32_t seq_len, void* embeds, void* stream);
