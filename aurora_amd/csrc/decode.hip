@@ -753,6 +753,8 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
                 if (a.ring == 1) return launch_skx_t<3, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
             }
             // (round 5: U = 8 at one column group - twice the weight bytes in flight per wave - is SLOWER: 20.1 -> 22.5 us at one slot)
+            // (also tried at one column group: 4 k phases per tile = 12 consumer waves instead of 6: 20.7 us against 20.1 - the QKV kernel at
+            // few slots is not short of bytes in flight)
             return launch_skx_t<3, 2, SK_QKV, NB, KC, 4, 4, 4>(a, gm, dim3(pairs, 1), s);
         }
         case SK_SILU_MUL:
@@ -815,6 +817,7 @@ static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
     switch (a.mode) {
         case SK_ROW:
             // few output tiles (N = hidden): 8 waves per workgroup double the loads in flight per CU
+            // (round 5: 16 waves on the o projection at 1 and 8 slots: 7.67 us against 7.55 with 8)
             if (a.waves == 8 && (a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8, NB>(a, s);
             return launch_skinny_t<1, SK_ROW, 4, NB>(a, s);
         case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS, 4, NB>(a, s);
@@ -1314,23 +1317,23 @@ __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b
     const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
     float M = -INFINITY;
     float num = 0.f, den = 0.f;
-    if (a.nsplit <= 16) {
-        // the engine's split counts (<= 16): every partial is fetched before the first is used - 3 x nsplit independent loads, one round
+    if (a.nsplit <= 32) {
+        // the engine's split counts (<= 16; <= 32 with --dec-attn-pps): every partial is fetched before the first is used - 3 x nsplit independent loads, one round
         // trip - then the same operations in the same order as the loop below (rounds 1-4 ran that loop for every count: 2 x nsplit
         // DEPENDENT round trips, 6.4 us per launch at one slot where the attention itself takes 8.9 us)
-        float m[16], l[16], o[16];
+        float m[32], l[32], o[32];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 32; ++s) {
             const int sc = s < a.nsplit ? s : a.nsplit - 1;
             m[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2);
             l[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2 + 1);
             o[s] = attn_part_ld<AGENT>(a.part_o + (p0 + sc) * a.hd + d);
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < 32; ++s)
             if (s < a.nsplit) M = fmaxf(M, m[s]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 32; ++s) {
             if (s >= a.nsplit || m[s] == -INFINITY) continue;
             const float wgt = __builtin_amdgcn_exp2f(m[s] - M);
             num = __builtin_fmaf(wgt, o[s], num);

@@ -689,7 +689,7 @@ def main():
                 return e0, evf, (front_seq[0], t_host), (ev_v, ev_p)
 
             def cycle(fill, timed):                                # noqa: F811 - the overlapped cycle replaces the sequential one
-                t_enq = time.perf_counter()
+                t_enq, c_enq = time.perf_counter(), time.thread_time()
                 for g in range(NG):
                     eng.slot_collect(g * G, G, ids_out[g], len_out[g])
                     e0, evf, t_host, (ev_v, ev_p) = pending[0]
@@ -746,6 +746,7 @@ def main():
                         sD.synchronize()
                 if timed:
                     host_enq["enqueue_s"] += time.perf_counter() - t_enq
+                    host_enq["enqueue_cpu_s"] = host_enq.get("enqueue_cpu_s", 0.0) + time.thread_time() - c_enq
                     host_enq["cycles"] += 1
                 got_ids, got_len = ids_out.cpu().numpy(), len_out.cpu().numpy()
                 o = [got_ids[g, j, :got_len[g, j]].tolist() for g in range(NG) for j in range(G)]
@@ -885,6 +886,12 @@ def main():
         dist.all_gather(allt, mine)
         per_rank_ms = [1e3 * float(t.item()) / args.steps for t in allt]
         elapsed = max(float(t.item()) for t in allt)
+        cyc = max(host_enq["cycles"], 1)
+        mine_h = torch.tensor([host_enq["enqueue_s"] / cyc, host_enq.get("enqueue_cpu_s", 0.0) / cyc, host_enq.get("cpu_s", 0.0) / args.steps],
+                              dtype=torch.float64, device=cdev)
+        allh = [torch.empty_like(mine_h) for _ in range(world)]
+        dist.all_gather(allh, mine_h)
+        host_enq["per_rank"] = [[float(x) for x in t.tolist()] for t in allh]
         fence()
         t_g = time.perf_counter()
         for _ in range(5):
@@ -947,6 +954,9 @@ def main():
         result["host"] = {
             "enqueue_s_per_cycle": (host_enq["enqueue_s"] / host_enq["cycles"]) if host_enq["cycles"] else None,
             "enqueue_frac_of_cycle": (host_enq["enqueue_s"] / host_enq["cycles"] / (elapsed / args.steps)) if host_enq["cycles"] else None,
+            "enqueue_thread_cpu_s_per_cycle": (host_enq["enqueue_cpu_s"] / host_enq["cycles"]) if host_enq.get("cycles") and "enqueue_cpu_s" in host_enq else None,
+            "per_rank": ([{"enqueue_s_per_cycle": a, "enqueue_thread_cpu_s_per_cycle": b, "process_cpu_s_per_cycle": c_} for a, b, c_ in host_enq["per_rank"]]
+                         if "per_rank" in host_enq else None),
             "process_cpu_s_per_cycle": (host_enq["cpu_s"] / args.steps) if "cpu_s" in host_enq else None,
             "process_cpu_util": (host_enq["cpu_s"] / elapsed) if "cpu_s" in host_enq else None,
             "cores_allowed": len(aff), "pinned_to_gpu_numa_cores": pinned,

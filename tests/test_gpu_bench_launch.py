@@ -189,3 +189,31 @@ def test_eight_rank_dry_run_of_the_configs3_command():
     d1 = _json_line(r1.stdout)
     assert d1["clips_of_rank0"][:4] == [3, 11, 19, 27]
     assert d1["ids_crc_per_clip"] == d["ids_crc_per_clip"][3::8]
+
+
+def test_eight_full_rate_enqueue_loops_share_one_host():
+    """on an 8-rank node the risk is the HOST - every rank's Python thread issues ~1.6e4 kernel launches and ~2.6e2
+    hipGraph replays per cycle of 128 captions.  Rehearsal without the node: `--tiny-deep` keeps the REAL layer counts (31 ViT + 32 Llama
+    layers, 128 slots, groups of 4, 256 tokens: the same launches per cycle as the metric's run) at tiny widths, so that eight such loops
+    run at full rate on this box's host (8 processes sharing its GPU, gloo).  The slowest rank's enqueue thread must need less than half
+    of the real cycle (9.0 s on one MI355X) of CPU per cycle - otherwise eight ranks on one host would be enqueue-bound."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["AURORA_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--tiny-deep", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-power", "--no-instrument"]
+    for attempt in range(2):
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=2400, env=env)
+        if r.returncode == 0:
+            break
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["clips_per_gpu_per_step"] == 128 and d["config"]["prefill_group"] == 4
+    per = d["host"]["per_rank"]
+    assert len(per) == 8
+    worst_cpu = max(p["enqueue_thread_cpu_s_per_cycle"] for p in per)
+    worst_wall = max(p["enqueue_s_per_cycle"] for p in per)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "eight_rank_enqueue_rehearsal.json"), "w") as f:
+        json.dump({"host": d["host"], "ms_per_step": d["ms_per_step"], "ms_per_step_per_rank": d["ms_per_step_per_rank"],
+                   "cores": os.cpu_count(), "note": "bench.py --gpus 8 --tiny-deep (gloo, 8 processes on one GPU): real launch counts, tiny kernels"}, f, indent=1)
+    print(f"\n8 ranks: slowest enqueue thread {worst_cpu:.2f} CPU-s per cycle ({worst_wall:.2f} s wall incl. queue back-pressure of the shared GPU)")
+    assert worst_cpu < 0.5 * 9.0, per

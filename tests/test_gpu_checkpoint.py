@@ -127,8 +127,9 @@ def test_fixture_not_written_by_this_repo_through_from_pretrained(visual, tmp_pa
         emb = out["inputs_embeds"][0].float().cpu()
         ref_emb = torch.from_numpy(g["embeds"])
         assert emb.shape == ref_emb.shape
+        from tests.parity_bounds import FEAT_TOL
         from tests.util import observe
-        observe("checkpoint/g13_spliced_embeds_rel_l2_vs_hf_reference_stack", ((emb - ref_emb).norm() / ref_emb.norm()).item(), 2e-2)   # ViT + ToMe + projector + splice in fp16 vs the fp32 stack
+        observe("checkpoint/g13_spliced_embeds_rel_l2_vs_hf_reference_stack", ((emb - ref_emb).norm() / ref_emb.norm()).item(), FEAT_TOL)   # ViT + ToMe + projector + splice in fp16 vs the fp32 stack
         got = m.llm.generate(**out, do_sample=False, num_beams=1, max_new_tokens=N, eos_token_id=None)[0].tolist()
         checked = assert_greedy_agrees_up_to_margin(got, g["ids"].tolist(), torch.from_numpy(g["logits"]), 1e-2)
         assert checked >= 8, (checked, got, g["ids"].tolist())

@@ -19,6 +19,16 @@ for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside 
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
+# 1b. (round 5) the kernels of the schedule the driver TIMES: the default overlapped continuous-batching loop itself,
+#     with the decode stream synchronised once per chunk (--sync-chunks: <= 8 graph replays queued, which the tracer survives; the
+#     synchronisation is off in timed runs and costs the traced run a few per cent).  One fill + one warm-up + one timed cycle.
+for attempt in 1 2 3; do
+  rm -rf "$OUT/trace_ov"
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ov" -o trace -- $BENCH --steps 1 --warmup 1 --sync-chunks --no-instrument --no-single-stream > "$OUT/trace_ov.log" 2>&1 && break
+done
+python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace_ov" "$OUT/${TAG}_kernel_stats_overlapped.txt" > /dev/null
+python "$REPO/tools/overlap_trace_summary.py" "$OUT/trace_ov" > "$OUT/${TAG}_overlap_trace_summary.txt" 2>&1
+tail -1 "$OUT/trace_ov.log" | cut -c1-300
 fi
 # counters serialise every dispatch.  Round 3: the pass runs at the DEFAULT batch (128 slots) with the default schedule's prefill groups
 # of 4 clips, so that every kernel is counted at the launch shape the bench line quotes it at (decode kernels at 128 rows and a context
