@@ -25,8 +25,8 @@
 //     by rstd[b] = rsqrt(sum/K + eps).
 //
 // decode attention: one wave per (sequence, head, split of 64-token pages).  K fragments (rows = tokens)
-//   and V^T fragments (rows = d) stream from the paged cache as contiguous 1 KiB pieces; q is replicated
-//   across the 16 MFMA columns.  S^T accumulators become the PAIRED-token P operand in-lane.
+//   and V^T fragments (rows = d) stream from the paged cache as contiguous 1 KiB pieces; dot products on the VALU (v_dot2c_f32_f16),
+//   one query per (sequence, head): see decode_attn_dot_kernel.
 #include "kernels.h"
 
 // address (halves) of the 16-byte piece holding x[b][k .. k+8) (k % 8 == 0) in x-fragment form
@@ -750,7 +750,7 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             if (N16 - gm.v_tile0 < pairs) return hipErrorInvalidValue;
             if constexpr (NB > 4) {
                 if (half && (pairs & 1) == 0) return launch_skx_t<6, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs / 2, 1), s);
-                if (a.ring == 1) return launch_skx_t<3, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);
+                return launch_skx_t<3, 2, SK_QKV, NB, 8, 2, 2, 4>(a, gm, dim3(pairs, 1), s);      // 5-8 column groups: 2 x 8 k32 ring (4 x 4 was 52.4 vs 55.8 us)
             }
             // (round 5: U = 8 at one column group - twice the weight bytes in flight per wave - is SLOWER: 20.1 -> 22.5 us at one slot)
             // (also tried at one column group: 4 k phases per tile = 12 consumer waves instead of 6: 20.7 us against 20.1 - the QKV kernel at
@@ -764,11 +764,11 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             if (a.gu_ks == 1) {
                 if constexpr (NB > 4) {
                     if (half) return launch_skx_t<11, 1, SK_SILU_MUL, NB, 4, 4, 4, 4>(a, gm, dim3(split(11, g_skx_cus / 2), 1), s);
-                    if (a.ring == 1) return launch_skx_t<6, 1, SK_SILU_MUL, NB, 8, 2, 8, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+                    return launch_skx_t<6, 1, SK_SILU_MUL, NB, 8, 2, 8, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
                 }
                 return launch_skx_t<6, 1, SK_SILU_MUL, NB, KC, 4, 8, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
             }
-            if (NB > 4 && a.ring == 1) return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 2, 4, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
+            if constexpr (NB > 4) return launch_skx_t<6, 2, SK_SILU_MUL, NB, 8, 2, 4, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
             return launch_skx_t<6, 2, SK_SILU_MUL, NB, KC, 4, 4, 4>(a, gm, dim3(split(6, g_skx_cus), 1), s);
         case SK_LOGITS: return launch_skx_t<8, 1, SK_LOGITS, NB, KC, 4, 4, 4>(a, gm, dim3(split(8, g_skx_cus), 1), s);
         case SK_ROW: {
@@ -951,368 +951,22 @@ hipError_t launch_xfrag_pack(const half_t* x, int64_t ldx, int rows, int d, half
 }
 
 // ------------------------------------------------------------------------------------ decode attention
-template <int KBLK, int VD16>
-__global__ __launch_bounds__(64) void decode_attn_kernel(DecAttnArgs a) {
-    const int lane = threadIdx.x;
-    const int g = lane >> 4;
-    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const KvLayout& kv = a.kv;
-    const int npos = a.pos[b] + 1;
-    const int seq = a.seq_ids ? a.seq_ids[b] : b;
-    const int npages = (npos + kv.page_tokens - 1) / kv.page_tokens;
-    const int p_first = sp * a.pages_per_split;
-    int p_last = p_first + a.pages_per_split;
-    p_last = p_last < npages ? p_last : npages;
-    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
-
-    h8 qf[KBLK];
-#pragma unroll
-    for (int blk = 0; blk < KBLK; ++blk)
-        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
-
-    f4 acc_o[VD16];
-#pragma unroll
-    for (int d = 0; d < VD16; ++d) acc_o[d] = f4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;
-
-    for (int p = p_first; p < p_last; ++p) {
-        const half_t* page = kv_page(kv, seq, p * kv.page_tokens);
-        for (int kb = 0; kb < (kv.page_tokens >> 6); ++kb) {
-            const int key0 = p * kv.page_tokens + kb * 64;
-            if (key0 >= npos) break;
-            h8 kf[4][KBLK];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int blk = 0; blk < KBLK; ++blk)
-                    kf[kt][blk] = __builtin_nontemporal_load((const h8*)(page + kfrag_off(kv, head, kb * 4 + kt, blk) + lane * 8));
-            h8 vf[VD16][2];
-#pragma unroll
-            for (int d = 0; d < VD16; ++d)
-#pragma unroll
-                for (int b32 = 0; b32 < 2; ++b32)
-                    vf[d][b32] = __builtin_nontemporal_load((const h8*)(page + vfrag_off(kv, head, d, kb * 2 + b32) + lane * 8));
-            f4 s[4];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                s[kt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int blk = 0; blk < KBLK; ++blk) s[kt] = mfma16(kf[kt][blk], qf[blk], s[kt]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = key0 + kt * 16 + 4 * g + i;
-                    const float v = key < npos ? s[kt][i] * sc : -INFINITY;
-                    s[kt][i] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-            mx = xor16_max(mx);
-            mx = xor32_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // key0 < npos => m_new finite
-            m_run = m_new;
-            h8 pf[2];
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kt][i] - m_new);
-                    ps += pv;
-                    pf[kt >> 1][(kt & 1) * 4 + i] = (half_t)pv;
-                }
-            l_run = l_run * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < VD16; ++d) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc_o[d][i] *= alpha;
-                acc_o[d] = mfma16(vf[d][0], pf[0], acc_o[d]);
-                acc_o[d] = mfma16(vf[d][1], pf[1], acc_o[d]);
-            }
-        }
-    }
-    float l = l_run;
-    l = xor16_sum(l);
-    l = xor32_sum(l);
-    if ((lane & 15) == 0) {
-#pragma unroll
-        for (int d = 0; d < VD16; ++d)
-            *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
-    }
-    if (lane == 0) {
-        a.part_ml[pidx * 2 + 0] = m_run;
-        a.part_ml[pidx * 2 + 1] = l;
-    }
-}
-
-// Variant 1: software-pipelined over 64-token pages.  While page p is being reduced (QK^T -> softmax -> PV),
-// its V fragments and page p+1's K fragments are already in flight (32 KiB per wave), so a wave never
-// idles for a full HBM round trip between its MFMA bursts.  Requires page_tokens == 64.
-// NT = true: non-temporal loads (the product path); false = default cache policy (lab: does the KV stream evict what the front
-// end's GEMMs keep in L2 / the memory-side cache?  tools/cumask/contention_lab.py, DecAttnArgs.variant == 2)
-template <bool NT>
-__device__ __forceinline__ h8 kv_load(const half_t* p) {
-    if constexpr (NT) return __builtin_nontemporal_load((const h8*)p);
-    else return *(const h8*)p;
-}
-template <int KBLK, int VD16, bool NT = true>
-__global__ __launch_bounds__(64) void decode_attn_pipe_kernel(DecAttnArgs a) {
-    const int lane = threadIdx.x;
-    const int g = lane >> 4;
-    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const KvLayout& kv = a.kv;
-    const int npos = a.pos[b] + 1;
-    const int seq = a.seq_ids ? a.seq_ids[b] : b;
-    const int npages = (npos + 63) >> 6;
-    const int p_first = sp * a.pages_per_split;
-    int p_last = p_first + a.pages_per_split;
-    p_last = p_last < npages ? p_last : npages;
-    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
-
-    h8 qf[KBLK];
-#pragma unroll
-    for (int blk = 0; blk < KBLK; ++blk)
-        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
-    f4 acc_o[VD16];
-#pragma unroll
-    for (int d = 0; d < VD16; ++d) acc_o[d] = f4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;
-    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;        // K frags of a (page, head): 4*KBLK contiguous KiB
-    const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;        // V frags: VD16*2 contiguous KiB
-
-    h8 kf[4 * KBLK], kn[4 * KBLK];
-    if (p_first < p_last) {
-        const half_t* page = kv_page(kv, seq, p_first * 64);
-#pragma unroll
-        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = kv_load<NT>(page + koff + i * AUR_FRAG_HALVES);
-    }
-    for (int p = p_first; p < p_last; ++p) {
-        const half_t* page = kv_page(kv, seq, p * 64);
-        h8 vf[VD16 * 2];
-#pragma unroll
-        for (int i = 0; i < VD16 * 2; ++i) vf[i] = kv_load<NT>(page + voff + i * AUR_FRAG_HALVES);
-        const bool more = p + 1 < p_last;                 // wave-uniform
-        if (more) {
-            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
-#pragma unroll
-            for (int i = 0; i < 4 * KBLK; ++i) kn[i] = kv_load<NT>(pn + koff + i * AUR_FRAG_HALVES);
-        }
-        const int key0 = p * 64;
-        f4 s[4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int blk = 0; blk < KBLK; ++blk) s[kt] = mfma16(kf[kt * KBLK + blk], qf[blk], s[kt]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = key0 + kt * 16 + 4 * g + i;
-                const float v = key < npos ? s[kt][i] * sc : -INFINITY;
-                s[kt][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-        mx = xor16_max(mx);
-        mx = xor32_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        h8 pf[2];
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(s[kt][i] - m_new);
-                ps += pv;
-                pf[kt >> 1][(kt & 1) * 4 + i] = (half_t)pv;
-            }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < VD16; ++d) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc_o[d][i] *= alpha;
-            acc_o[d] = mfma16(vf[d * 2 + 0], pf[0], acc_o[d]);
-            acc_o[d] = mfma16(vf[d * 2 + 1], pf[1], acc_o[d]);
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = kn[i];
-        }
-    }
-    float l = l_run;
-    l = xor16_sum(l);
-    l = xor32_sum(l);
-    if (a.nsplit == 1) {
-        // one split covers the whole context (engines whose batch alone fills the GPU: sequences x heads >= 512 waves): the
-        // wave owns the final softmax, so it writes the attention output itself, straight in x-fragment form (input of the o
-        // projection) - no partials, no combine launch (4.7 us + a kernel boundary per layer-step at 64 sequences)
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int d = 0; d < VD16; ++d) {
-                const int k = head * a.hd + d * 16 + 4 * g;
-                h4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc_o[d][i] / l);
-                *(h4*)(a.out_f + xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)) = o;
-            }
-        }
-        return;
-    }
-    if ((lane & 15) == 0) {
-#pragma unroll
-        for (int d = 0; d < VD16; ++d) *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
-    }
-    if (lane == 0) {
-        a.part_ml[pidx * 2 + 0] = m_run;
-        a.part_ml[pidx * 2 + 1] = l;
-    }
-}
-
-// Variant 3: the same page pipeline with HALF the register footprint -> two waves per SIMD.  decode_attn_pipe_kernel double-buffers K
-// in registers (kf + kn + vf = 192 VGPRs of operands: 290 with the rest, one wave per SIMD, 128 KiB of loads in flight per CU).  On the
-// 16 CUs per XCD the decode stream owns while a front end runs, the kernel is bound by bytes in flight per CU (6.4 TB/s on 128 CUs against
-// 7.3 TB/s on 256), so this variant re-loads K(p + 1) into the SAME registers as soon as the Q K^T products of page p have been issued:
-// the loads have the softmax and the P V products of page p to land.  128 VGPRs of operands, <= 256 in all, 8 waves per CU, up to 256 KiB in
-// flight.  Same operations in the same order: bitwise the result of variant 1.
-template <int KBLK, int VD16>
-__global__ __launch_bounds__(64, 2) void decode_attn_pipe2_kernel(DecAttnArgs a) {
-    const int lane = threadIdx.x;
-    const int g = lane >> 4;
-    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const KvLayout& kv = a.kv;
-    const int npos = a.pos[b] + 1;
-    const int seq = a.seq_ids ? a.seq_ids[b] : b;
-    const int npages = (npos + 63) >> 6;
-    const int p_first = sp * a.pages_per_split;
-    int p_last = p_first + a.pages_per_split;
-    p_last = p_last < npages ? p_last : npages;
-    const int64_t pidx = ((int64_t)b * a.heads + head) * a.nsplit + sp;
-
-    h8 qf[KBLK];
-#pragma unroll
-    for (int blk = 0; blk < KBLK; ++blk)
-        qf[blk] = *(const h8*)(a.qbuf + ((((int64_t)b * a.heads + head) * KBLK + blk) * 4 + g) * 8);
-    f4 acc_o[VD16];
-#pragma unroll
-    for (int d = 0; d < VD16; ++d) acc_o[d] = f4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;
-    const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;
-    const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;
-
-    h8 kf[4 * KBLK];
-    if (p_first < p_last) {
-        const half_t* page = kv_page(kv, seq, p_first * 64);
-#pragma unroll
-        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
-    }
-    for (int p = p_first; p < p_last; ++p) {
-        const half_t* page = kv_page(kv, seq, p * 64);
-        h8 vf[VD16 * 2];
-#pragma unroll
-        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
-        const bool more = p + 1 < p_last;                 // wave-uniform
-        const int key0 = p * 64;
-        f4 s[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int blk = 0; blk < KBLK; ++blk) s[kt] = mfma16(kf[kt * KBLK + blk], qf[blk], s[kt]);
-        }
-        if (more) {                                       // K of the next page into the registers the products above have just read
-            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
-#pragma unroll
-            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = key0 + kt * 16 + 4 * g + i;
-                const float v = key < npos ? s[kt][i] * sc : -INFINITY;
-                s[kt][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = xor16_max(mx);
-        mx = xor32_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        h8 pf[2];
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(s[kt][i] - m_new);
-                ps += pv;
-                pf[kt >> 1][(kt & 1) * 4 + i] = (half_t)pv;
-            }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < VD16; ++d) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc_o[d][i] *= alpha;
-            acc_o[d] = mfma16(vf[d * 2 + 0], pf[0], acc_o[d]);
-            acc_o[d] = mfma16(vf[d * 2 + 1], pf[1], acc_o[d]);
-        }
-    }
-    float l = l_run;
-    l = xor16_sum(l);
-    l = xor32_sum(l);
-    if (a.nsplit == 1) {
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int d = 0; d < VD16; ++d) {
-                const int k = head * a.hd + d * 16 + 4 * g;
-                h4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc_o[d][i] / l);
-                *(h4*)(a.out_f + xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)) = o;
-            }
-        }
-        return;
-    }
-    if ((lane & 15) == 0) {
-#pragma unroll
-        for (int d = 0; d < VD16; ++d) *(f4*)(a.part_o + pidx * a.hd + d * 16 + 4 * g) = acc_o[d];
-    }
-    if (lane == 0) {
-        a.part_ml[pidx * 2 + 0] = m_run;
-        a.part_ml[pidx * 2 + 1] = l;
-    }
-}
-
-// Variant 4: the same page pipeline on the VALU (v_dot2c_f32_f16) instead of the matrix cores.  One query per (sequence, head) makes the
-// decode attention a GEMV: the MFMA forms above replicate q over the 16 columns of a 16x16x32 tile and throw 15 / 16 of every
-// product away - 32 MFMAs = 524 k MACs per 32 KiB page for 16 k useful ones.  Measured (tools/cumask/power_lab.py): the kernel draws
-// 1200 W at 7.3 TB/s where a bare read stream of the same rate draws ~1000 W, and the serving schedule runs AT the 1400 W socket cap
-// (DESIGN section 4): those watts are throughput.  Here a lane keeps the layout the fragments give it - lane (g, r) holds token
-// kt * 16 + r x the 8 PAIRED dims of group g of a K fragment, feature d16 * 16 + r x the 8 PAIRED tokens of group g of a V^T fragment:
+// One wave per (sequence, head, split of 64-token pages), on the VALU (v_dot2c_f32_f16).  One query per (sequence, head) makes the decode
+// attention a GEMV: an MFMA form (rounds 1-3: q replicated over the 16 columns of a 16x16x32 tile; docs/rounds/r01-r04.md section 4)
+// throws 15 / 16 of every product away - 32 MFMAs = 524 k MACs per 32 KiB page for 16 k useful ones, and 12-20 W of a socket that runs
+// at its power cap.  A lane keeps the layout the fragments give it - lane (g, r) holds token kt * 16 + r x the 8 PAIRED dims of group g
+// of a K fragment, feature d16 * 16 + r x the 8 PAIRED tokens of group g of a V^T fragment:
 //   Q K^T : 4 v_dot2c per fragment into ONE fp32 per (lane, kt); the 4 dim groups of a token meet by two row exchanges (xor 16, 32)
-//   softmax: 4 scores per lane instead of 16 (the MFMA accumulators held every score four times over)
+//   softmax: 4 scores per lane
 //   P     : 64 probabilities -> LDS as fp16 in token order (lane l writes token l), read back as the PAIRED token groups of the V^T
 //           fragments (two 8-byte reads per 32 tokens): 128 B of LDS per wave, same wave writes and reads - no barrier
 //   P V   : 4 v_dot2c per fragment into one fp32 per (lane, d16); the 4 token groups meet once, after the last page
-// 128 dot products + ~40 other VALU operations per page instead of 32 MFMAs + ~250; registers as variant 3 (two waves per SIMD).
-// Different summation order than variants 0 / 1 / 3 (not bitwise equal to them); deterministic and batch-invariant like them.
+// Software-pipelined over pages: K of page p + 1 is re-loaded into the registers the Q K^T products of page p have just read, V of page p
+// is in flight with it (<= 256 registers: two waves per SIMD, up to 256 KiB of loads in flight per CU).  Deterministic, batch-invariant.
 // One output feature d of (sequence b, head): the splits' partials combined in the fixed order s = 0, 1, .. (deterministic whatever order
-// they were produced in).  Shared by decode_attn_combine_kernel and by the in-kernel combine of decode_attn_dot_kernel: the same
-// instructions, hence the same bits.  AGENT = the partials were published at agent scope by other workgroups of THIS launch: read them
-// with L1-bypassing (sc1) loads.
-template <bool AGENT>
-__device__ __forceinline__ float attn_part_ld(const float* p) {
-    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <bool AGENT>
+// they were produced in).  (Rounds 4-5 also had the last-arriving split combine inside the attention kernel, behind an agent-scope
+// hand-over: bitwise the same, 0.3 % slower at 8 slots and 7 % slower at one - removed.)
+__device__ __forceinline__ float attn_part_ld(const float* p) { return *p; }
 __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b, int head, int d) {
     const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
     float M = -INFINITY;
@@ -1325,9 +979,9 @@ __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int sc = s < a.nsplit ? s : a.nsplit - 1;
-            m[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2);
-            l[s] = attn_part_ld<AGENT>(a.part_ml + (p0 + sc) * 2 + 1);
-            o[s] = attn_part_ld<AGENT>(a.part_o + (p0 + sc) * a.hd + d);
+            m[s] = attn_part_ld(a.part_ml + (p0 + sc) * 2);
+            l[s] = attn_part_ld(a.part_ml + (p0 + sc) * 2 + 1);
+            o[s] = attn_part_ld(a.part_o + (p0 + sc) * a.hd + d);
         }
 #pragma unroll
         for (int s = 0; s < 32; ++s)
@@ -1340,13 +994,13 @@ __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b
             den = __builtin_fmaf(wgt, l[s], den);
         }
     } else {
-        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2));
+        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, attn_part_ld(a.part_ml + (p0 + s) * 2));
         for (int s = 0; s < a.nsplit; ++s) {
-            const float m = attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2);
+            const float m = attn_part_ld(a.part_ml + (p0 + s) * 2);
             if (m == -INFINITY) continue;
             const float wgt = __builtin_amdgcn_exp2f(m - M);
-            num = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_o + (p0 + s) * a.hd + d), num);
-            den = __builtin_fmaf(wgt, attn_part_ld<AGENT>(a.part_ml + (p0 + s) * 2 + 1), den);
+            num = __builtin_fmaf(wgt, attn_part_ld(a.part_o + (p0 + s) * a.hd + d), num);
+            den = __builtin_fmaf(wgt, attn_part_ld(a.part_ml + (p0 + s) * 2 + 1), den);
         }
     }
     const int k = head * a.hd + d;                 // attention output in x-fragment form (input of the o projection)
@@ -1467,73 +1121,32 @@ __global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
         }
         return;
     }
-    if (a.cnt == nullptr) {                              // decode_attn_combine_kernel follows
-#pragma unroll
-        for (int d = 0; d < VD16; ++d)
-            if ((d & 3) == g) a.part_o[pidx * a.hd + d * 16 + r] = acc_o[d];
-        if (lane == 0) {
-            a.part_ml[pidx * 2 + 0] = m_run;
-            a.part_ml[pidx * 2 + 1] = l;
-        }
-        return;
-    }
-    // ---- combine IN the kernel (round 4; engines whose batch alone does not fill the GPU run 2-16 splits per (sequence, head) and paid a
-    // second launch per layer for a 3 us kernel: 32 of the 225 launches of an 8-slot decode step).  The guide's in-launch hand-over in
-    // its counter form (Guideline 16 / the split-K recipe): every split publishes its partial with write-through agent-scope stores
-    // (compiler-emitted atomics: hipcc pads and counts them - section 10.2 of DESIGN.md is what an inline-asm store did here), drains them
-    // (this block is ONE wave), counts itself in; the split that finds the pair complete reads all partials back with sc1 loads and
-    // combines them in the fixed order s = 0, 1, .. with the SAME function as the separate kernel - bitwise its result.  Placement-
-    // independent: nothing assumes where or when the other splits ran.  The counter returns to zero for the next launch / graph replay.
+    // decode_attn_combine_kernel follows
 #pragma unroll
     for (int d = 0; d < VD16; ++d)
-        if ((d & 3) == g) __hip_atomic_store(a.part_o + pidx * a.hd + d * 16 + r, acc_o[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((d & 3) == g) a.part_o[pidx * a.hd + d * 16 + r] = acc_o[d];
     if (lane == 0) {
-        __hip_atomic_store(a.part_ml + pidx * 2 + 0, m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.part_ml + pidx * 2 + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.part_ml[pidx * 2 + 0] = m_run;
+        a.part_ml[pidx * 2 + 1] = l;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial has reached the coherence point before the arrival is counted
-    int last = 0;
-    if (lane == 0) {
-        int* c = a.cnt + b * a.heads + head;
-        const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = arrived == a.nsplit - 1;
-        if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last) return;
-    for (int d = lane; d < a.hd; d += 64) attn_combine_feature<true>(a, b, head, d);
 }
 
 __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     if (d >= a.hd) return;
-    attn_combine_feature<false>(a, b, head, d);
+    attn_combine_feature(a, b, head, d);
 }
 
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
-    if (a.kv.page_tokens & 63) return hipErrorInvalidValue;
+    if (a.kv.page_tokens != 64) return hipErrorInvalidValue;        // the page pipeline is written for 64-token pages (aur_create enforces it)
     dim3 grid(a.nsplit, a.heads, a.B);
-    const bool pipe = a.variant >= 1 && a.kv.page_tokens == 64;
-    if (a.variant == 2 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8, false>), grid, dim3(64), 0, s, a);
-    else if (a.variant == 3 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe2_kernel<4, 8>), grid, dim3(64), 0, s, a);
-    else if (a.variant == 4 && pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8>), grid, dim3(64), 0, s, a);
-    else if (a.variant == 4 && pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_dot_kernel<1, 2>), grid, dim3(64), 0, s, a);
-    else if (a.variant == 4 && pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_dot_kernel<2, 4>), grid, dim3(64), 0, s, a);
-    else if (pipe && a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 8>), grid, dim3(64), 0, s, a);
-    else if (pipe && a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_pipe_kernel<2, 4>), grid, dim3(64), 0, s, a);
-    else if (pipe && a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_pipe_kernel<1, 2>), grid, dim3(64), 0, s, a);
-    else if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_kernel<4, 8>), grid, dim3(64), 0, s, a);
-    else if (a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_kernel<2, 4>), grid, dim3(64), 0, s, a);
-    else if (a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_kernel<1, 2>), grid, dim3(64), 0, s, a);
+    if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8>), grid, dim3(64), 0, s, a);
+    else if (a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_dot_kernel<2, 4>), grid, dim3(64), 0, s, a);
+    else if (a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_dot_kernel<1, 2>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-bool decode_attention_needs_combine(const DecAttnArgs& a) {
-    // the pipelined kernels finish single-split problems themselves (see their epilogues); variant 4 with arrival counters combines in the kernel
-    if (a.nsplit == 1 && a.variant >= 1 && a.kv.page_tokens == 64) return false;
-    if (a.cnt != nullptr && a.variant == 4 && a.kv.page_tokens == 64) return false;
-    return true;
-}
+bool decode_attention_needs_combine(const DecAttnArgs& a) { return a.nsplit > 1; }     // a single split normalises and stores its output itself
 hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
     if (!decode_attention_needs_combine(a)) return hipSuccess;
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.heads, a.B), dim3(a.hd <= 64 ? 64 : 128), 0, s, a);

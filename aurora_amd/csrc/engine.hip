@@ -77,16 +77,14 @@ struct aur_ctx {
     int32_t* ptab_rw() { return const_cast<int32_t*>(ptab_cur); }
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
-    int attn_variant = 4, row_waves = 8, last_prefill_len = 0, mb_nseq = 1;      // tuning knobs (aur_set_option); decode attention: 4 = VALU dot products (decode.hip)
+    int row_waves = 8, last_prefill_len = 0, mb_nseq = 1;                         // tuning knobs (aur_set_option)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
     int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1, gemm_nt_out = -1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
-    int skinny_variant = 0, row_split_min_k = 8192, skinny_ring = 1;                             // decode projections: x through LDS (engines of > 32 slots)
+    int skinny_variant = 0, row_split_min_k = 8192;                             // decode projections: x through LDS (engines of > 32 slots)
     int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
-    int* d_attn_cnt = nullptr;                                                  // [max_batch][heads] arrival counters of the decode attention's in-kernel combine
     int tome_fused_ln = 1;                                                      // 1: LayerNorm 2 of a merging ViT layer comes out of the ToMe merge launch (bitwise norm_kernel's result; 0 = its own launch, A/B and test only)
-    int attn_fused_combine = 0;                                                 // 1: the last-arriving split of a (sequence, head) combines in the attention kernel (bitwise the same; measured 0.3 % slower at 8 slots than the launch it saves)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
@@ -283,7 +281,6 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
     c->d_row_cnt = k.take<int>(c->l_dpad / 16);
-    c->d_attn_cnt = k.take<int>(B * g.llm_heads);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
@@ -305,7 +302,7 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
     if (g.llm_hidden % 128 || g.llm_mlp % 128 || g.llm_hidden % g.llm_heads || (g.llm_hidden / g.llm_heads) % 32)
         return aur_fail(nullptr, AUR_ERR_ARG, "llm dims: hidden/mlp must be multiples of 128, head_dim a multiple of 32");
     if (g.max_batch < 1 || g.max_batch > AUR_MAX_BATCH) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, %d]", AUR_MAX_BATCH);
-    if (g.page_tokens < 64 || g.page_tokens % 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be a multiple of 64");
+    if (g.page_tokens != 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be 64 (the decode attention's page pipeline is written for 64-token pages)");
     if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
     if (g.vit_native_image < 0 || g.vit_native_image > g.vit_image || g.vit_native_image % g.vit_patch)
         return aur_fail(nullptr, AUR_ERR_ARG, "vit_native_image must be 0 or a multiple of the patch size <= vit_image");
@@ -366,7 +363,6 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     carve(ctx, ctx->ws);
     ctx->finalized = false;
     if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
-    if (ctx->d_attn_cnt) CK(hipMemset(ctx->d_attn_cnt, 0, (size_t)ctx->cfg.max_batch * ctx->cfg.llm_heads * 4));
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -1131,7 +1127,7 @@ static SkinnyArgs mk_dec_qkv(aur_ctx* ctx, int l) {
     q.ssq_in = ctx->s_ssq_mlp; q.norm_eps = g.llm_rms_eps; q.ssq_zero = ctx->s_ssq_attn;
     q.xf = ctx->d_x; q.W = ctx->ll[l].qkv_w; q.B = ctx->batch; q.b_lo = 0; q.b_hi = ctx->batch; q.Npad = ctx->l_qkv_npad; q.K = d;
     q.n_real = 3 * d; q.mode = SK_QKV; q.q_cols = d; q.k_cols = d; q.hd = ctx->l_hd; q.qbuf = ctx->d_q; q.kv = llm_kv(ctx, l);
-    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant_wide; q.ring = ctx->skinny_ring;
+    q.rope = ctx->l_rope; q.pos = ctx->s_pos; q.seq_ids = nullptr; q.variant = ctx->skinny_variant_wide;
     q.half_grid = ctx->decode_half;
     return q;
 }
@@ -1140,8 +1136,7 @@ static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
     DecAttnArgs at{};
     at.qbuf = ctx->d_q; at.kv = llm_kv(ctx, l); at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = ctx->batch; at.heads = g.llm_heads;
     at.hd = ctx->l_hd; at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
-    at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32; at.variant = ctx->attn_variant;
-    at.cnt = (ctx->attn_fused_combine && ctx->attn_variant == 4 && ctx->nsplit > 1) ? ctx->d_attn_cnt : nullptr;
+    at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32;
     return at;
 }
 static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
@@ -1159,7 +1154,7 @@ static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
     SkinnyArgs gu{};
     gu.ssq_in = ctx->s_ssq_attn; gu.norm_eps = g.llm_rms_eps; gu.ssq_zero = ctx->s_ssq_mlp;
     gu.xf = ctx->d_x; gu.W = ctx->ll[l].gateup_w; gu.B = ctx->batch; gu.b_lo = 0; gu.b_hi = ctx->batch; gu.Npad = ctx->l_gu_npad; gu.K = d;
-    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant_wide; gu.ring = ctx->skinny_ring;
+    gu.n_real = 2 * g.llm_mlp; gu.mode = SK_SILU_MUL; gu.out_f = ctx->d_h; gu.out_k32 = g.llm_mlp / 32; gu.variant = ctx->skinny_variant_wide;
     gu.gu_ks = g.max_batch > 64 ? 1 : 2; gu.half_grid = ctx->decode_half;
     return gu;
 }
@@ -1297,11 +1292,9 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         ctx->tome_fused_ln = value ? 1 : 0;
         return AUR_OK;
     }
-    if (!strcmp(name, "dec_attn_variant")) ctx->attn_variant = (int)value;
-    else if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
+    if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = ctx->skinny_variant_wide = value ? 1 : 0;
     else if (!strcmp(name, "skinny_variant_wide")) ctx->skinny_variant_wide = value ? 1 : 0;
-    else if (!strcmp(name, "skinny_ring")) ctx->skinny_ring = (int)value;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strncmp(name, "gemm_", 5) || !strcmp(name, "microbench_prefill_nseq")) {
         // GEMM knobs: no GEMM is part of the captured decode step (its projections are the skinny kernels), so the graphs stay
@@ -1310,7 +1303,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
         else if (!strcmp(name, "gemm_nt_out")) ctx->gemm_nt_out = value < 0 ? -1 : (value ? 1 : 0);
         else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
-        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value >= 0 && value <= 2) ? (int)value : 1;
+        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value == 0 || value == 1) ? (int)value : 1;
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
         else if (!strcmp(name, "gemm_lab")) {
 #ifdef AUR_LABS
@@ -1327,10 +1320,6 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 1) return aur_fail(ctx, AUR_ERR_ARG, "dec_attn_pps must be >= 1");
         ctx->pps = (int)value;
         ctx->nsplit = (ctx->l_max_pages + (int)value - 1) / (int)value;
-    } else if (!strcmp(name, "dec_attn_fused_combine")) {
-        // 0 (default): decode_attn_combine_kernel combines the splits of a (sequence, head) in a second launch; 1: the split that arrives
-        // last combines them inside the attention kernel (decode.hip).  Bitwise the same output.
-        ctx->attn_fused_combine = value ? 1 : 0;
     } else if (!strcmp(name, "decode_fused_reduce")) {
         // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (the last-arriving split reduces;
         // decode.hip "split-K with the reduce IN the kernel"); 0: a second launch does (skinny_row_reduce_kernel).  Bitwise the same tokens.

@@ -52,7 +52,7 @@
 #ifndef G2_SCHED
 #define G2_SCHED 2      // round 4: +3..6 % on every shape of the path against schedule 0 (profiles/r04_gemm_segments.log), same bits
 #endif
-// ---- lab instantiations (tools/cumask/contention_lab.py; never launched by the product path: GemmArgs.lab == 0 there).
+// ---- lab instantiations (round 3: tools/cumask/contention_lab.py, now in the history; never launched by the product path: GemmArgs.lab == 0 there).
 // TAG >= GT_LAB_BASE selects a deliberately altered kernel that answers "what does the front-end GEMM take away from a concurrent
 // decode stream?": cache-policy bits on the operand DMAs, no DMA at all (power / clock only), no MFMA (fabric traffic only), or the
 // activation operand read from a K-tile-major image (DRAM-friendly 32 KiB blocks instead of 128-byte row pieces; results are garbage).
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     // are 4 (M) x 8 (N) and nothing is shared between XCDs in time.  gridDim.x is a multiple of 8 whenever a workgroup walks more than
     // one tile, so its tiles keep the XCD (bid % 8) both orders assume.
     TileOrder ord;
-    tile_order_init(ord, nbm, nbn, a.tile_order >= 1 ? (int)gridDim.x : 0, a.tile_order == 2 ? 2 : 1);
+    tile_order_init(ord, nbm, nbn, a.tile_order >= 1 ? (int)gridDim.x : 0);
     auto tile_of = [&](int bid, int& bm, int& bn) {
         if (ord.full > 0 || a.tile_order >= 1) {
             tile_of_bid(ord, bid, bm, bn);
@@ -732,7 +732,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     if (ntiles > cap) ntiles = cap;
     dim3 grid(ntiles), block(512);
 #define G2_LAUNCH(E, T) hipLaunchKernelGGL((gemm256_kernel<E, T>), grid, block, G2_LDS, s, a)
-    if (epi == EPI_ROW && a.lab > 0) {            // lab instantiations only (contention_lab.py)
+    if (epi == EPI_ROW && a.lab > 0) {            // lab instantiations only
 #ifndef AUR_LABS
         return hipErrorInvalidValue;
 #else

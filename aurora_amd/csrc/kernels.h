@@ -33,8 +33,7 @@ struct GemmArgs {
     int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
     int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
     int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
-    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges,
-                            // 2 = hand-down: an XCD keeps its band of M-tiles, weight column groups pass from XCD to XCD round by round
+    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
     int nt_out;             // 1 = the output of this launch is larger than the L2s together: written with non-temporal stores (ctx_gemm)
     int lab;                // 0 in the product path; > 0 = lab instantiation of the 256x256 kernel (gemm256.hip G2Lab, EPI_ROW only)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
@@ -156,7 +155,6 @@ struct SkinnyArgs {
     // structure: 0 = x fragments per wave from L2 (engines of <= 32 decode slots), 1 = x through LDS once per workgroup
     // (decode.hip "skinny GEMM, x through LDS").  Chosen per ENGINE (capacity), never per live batch: batch invariance.
     int variant;
-    int ring;               // variant 1, > 64 rows: 0 = 4 x (4 k32) x-ring buffers, 1 = 2 x (8 k32): fewer barriers, measured 52.4 vs 55.8 us (QKV) and 46.2 vs 49.7 us (gate/up) at 128 rows
     float* part;            // variant 1, SK_ROW: split-K partials [4][Npad/16][ceil(B/16)][64][4] fp32 (nullptr: keep structure 0)
     int* row_cnt;           // variant 1, SK_ROW: arrival counters [Npad/16], zero between launches: the workgroup that completes a tile's 4
                             // partials sums them (fixed order) and runs the residual epilogue IN the projection kernel.  nullptr = a second
@@ -186,9 +184,6 @@ struct DecAttnArgs {
     float* part_ml;         // [B][heads][nsplit][2]
     half_t* out_f;          // [B, heads*hd] in x-fragment form (K32 = out_k32 = heads*hd/32)
     int out_k32;
-    int variant;            // 0: load-use per page; 1: software-pipelined (next page's K + this page's V in flight)
-    int* cnt;               // [B][heads] arrival counters, zero between launches (variant 4, nsplit > 1): the split that finds its
-                            // (sequence, head) complete combines the partials IN the attention kernel; nullptr = decode_attn_combine_kernel follows
 };
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);            // main + combine
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s);

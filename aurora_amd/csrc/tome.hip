@@ -326,28 +326,16 @@ __global__ __launch_bounds__(1024) void tome_select_kernel(const float* __restri
 
 // ------------------------------------------------------------------ merge (tome.py:71-81, 207-219) (+ LayerNorm 2, aurora.py:750)
 // One wave per output row; a lane owns chunks lane, lane + 64, ... of V halves (V = 8: 16-byte loads / stores when d % 8 == 0).
-// Sum order per element: the B (or unmerged A) row first, then the merged A rows in rank order - as the oracle does.  The frame's
-// src / dst lists are staged in LDS once per workgroup.  LN: the normalised row is written beside the merged one from the registers
+// Sum order per element: the B (or unmerged A) row first, then the merged A rows in rank order - as the oracle does.  LN: the normalised row is written beside the merged one from the registers
 // that hold it - norm.hip's norm_kernel<false> on the ROUNDED fp16 row, operation for operation (its two FMAs are explicit there).
 #define TM_ROWS 4       // output rows per workgroup: one per wave
 template <int V, int MAXC, bool LN>
 __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
     typedef half_t hv __attribute__((ext_vector_type(V)));
-    extern __shared__ __attribute__((aligned(16))) int lsm[];        // [r] src, [r] dst
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.y;
     const int ta = (a.t + 1) >> 1, nu = ta - a.r, t_out = a.t - a.r;
-    int* srcl = lsm;
-    int* dstl = lsm + a.r;
     const int o = blockIdx.x * TM_ROWS + wave;
-    const bool b_rows = (blockIdx.x * TM_ROWS + TM_ROWS - 1) >= nu;  // some wave of this workgroup owns a B row: it needs the lists
-    if (b_rows) {
-        for (int q = tid; q < a.r; q += 256) {
-            srcl[q] = a.src[(int64_t)f * a.r + q];
-            dstl[q] = a.dst[(int64_t)f * a.r + q];
-        }
-        __syncthreads();
-    }
     if (o >= a.t_out_pad) return;
     const int nchunk = a.d / V;
     const half_t* xf = a.x + (int64_t)f * a.t_pad * a.d;
@@ -363,6 +351,14 @@ __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[i][j] = 0.f;
     } else {
+        // (B rows: the first 64 (dst, src) pairs are requested BEFORE the row itself, so that all of the wave's loads share one round trip)
+        const int32_t* dstf = a.dst + (int64_t)f * a.r;
+        const int32_t* srcf = a.src + (int64_t)f * a.r;
+        int my_dst = -1, my_src = 0;
+        if (o >= nu && lane < a.r) {
+            my_dst = dstf[lane];
+            my_src = srcf[lane];
+        }
         const int tok = o < nu ? 2 * a.unm[(int64_t)f * nu + o] : 2 * (o - nu) + 1;
         const float s0 = sf ? sf[tok] : 1.0f;
         st = s0;
@@ -376,24 +372,36 @@ __global__ __launch_bounds__(256) void tome_merge_kernel(TomeArgs a) {
             }
         }
         if (o >= nu) {
+            // the frame's (dst, src) pairs, 64 per pass: lane q holds pair q (one load each, in flight beside the row's own loads above -
+            // a first version staged the lists in LDS behind a barrier: one more dependent round trip per workgroup); the pairs that
+            // merge into this row are the set bits of a ballot, visited in ascending q = rank order
             const int jrow = o - nu;
-            for (int q = 0; q < a.r; ++q) {
-                if (dstl[q] != jrow) continue;
-                const int tsq = 2 * srcl[q];
-                const float ss = sf ? sf[tsq] : 1.0f;
+            for (int q0 = 0; q0 < a.r; q0 += 64) {
+                if (q0 > 0) {
+                    const int q = q0 + lane;
+                    my_dst = q < a.r ? dstf[q] : -1;
+                    my_src = q < a.r ? srcf[q] : 0;
+                }
+                unsigned long long hits = __ballot(my_dst == jrow);
+                while (hits) {
+                    const int bq = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const int tsq = 2 * __builtin_amdgcn_readlane(my_src, bq);
+                    const float ss = sf ? sf[tsq] : 1.0f;
 #pragma unroll
-                for (int i = 0; i < MAXC; ++i) {
-                    const int c = lane + i * 64;
-                    if (c < nchunk) {
-                        const hv v = *(const hv*)(xf + (int64_t)tsq * a.d + c * V);
+                    for (int i = 0; i < MAXC; ++i) {
+                        const int c = lane + i * 64;
+                        if (c < nchunk) {
+                            const hv v = *(const hv*)(xf + (int64_t)tsq * a.d + c * V);
 #pragma unroll
-                        for (int j = 0; j < V; ++j) {
-                            const float p = (float)v[j] * ss;
-                            acc[i][j] = acc[i][j] + p;
+                            for (int j = 0; j < V; ++j) {
+                                const float p = (float)v[j] * ss;
+                                acc[i][j] = acc[i][j] + p;
+                            }
                         }
                     }
+                    st = st + ss;
                 }
-                st = st + ss;
             }
         }
     }
@@ -492,7 +500,7 @@ hipError_t launch_tome_step(const TomeArgs& a, hipStream_t s) {
     const size_t lds_s = (size_t)((ta + 15) & ~15) * 8 + (size_t)(ta + a.r + 4) * 4;      // keys (8 bytes each) + ranks + src list
     hipLaunchKernelGGL(tome_select_kernel, dim3(a.frames), dim3(1024), lds_s, s, a.node_max, a.node_idx, a.t, a.r, a.unm, a.src, a.dst);
     const dim3 grid((a.t_out_pad + TM_ROWS - 1) / TM_ROWS, a.frames);
-    const size_t lds = (size_t)(2 * a.r + 4) * 4;
+    const size_t lds = 0;
     if ((a.d & 7) == 0) {
         if (a.ln_out) hipLaunchKernelGGL((tome_merge_kernel<8, 4, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((tome_merge_kernel<8, 4, false>), grid, dim3(256), lds, s, a);

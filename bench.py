@@ -94,9 +94,8 @@ def parse():
                    help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
                         "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
     p.add_argument("--gemm-tail-split", type=int, default=-1, help="A/B: 0 = one 256x256 launch per GEMM, 1 = idle last rounds go to the 128x128 kernel")
-    p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs")
+    p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs (default)")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
-    p.add_argument("--dec-attn-variant", type=int, default=-1, help="A/B: decode attention kernel (1 MFMA page pipeline, 3 the same with two waves per SIMD, 4 VALU dot products)")
     p.add_argument("--prune-last", type=int, default=-1, help="A/B: 0 = the last prefill layer computes every row (as HF does), 1 (engine default) = K / V for every "
                    "row, the rest for each sequence's last 128 rows only (bitwise the same outputs)")
     p.add_argument("--fused-reduce", type=int, default=-1, help="A/B: 0 (engine default) = the split-K residual projections (o, down) are followed by a reduce launch, 1 = "
@@ -104,8 +103,6 @@ def parse():
     p.add_argument("--gemm-nt-out", type=int, default=-1, help="A/B: GEMM output stores 0 = default cache policy, 1 = non-temporal, -1 (engine default) = non-temporal "
                    "for outputs larger than the L2s together")
     p.add_argument("--dec-attn-pps", type=int, default=0, help="A/B: KV pages per decode-attention split (0 = the engine's choice: ~512 waves on the GPU)")
-    p.add_argument("--attn-fused-combine", type=int, default=-1, help="A/B: 0 (engine default) = decode_attn_combine_kernel follows the VALU decode attention as its own "
-                   "launch, 1 = the last-arriving split combines the partials in the kernel")
     p.add_argument("--sync-front", action="store_true", help="batch mode: synchronise after every prefill group (profiling aid: keeps the queue of pending "
                                                             "launches short - rocprofv3's counter mode crashed with ~11 k launches queued ahead of the GPU)")
     p.add_argument("--no-power", action="store_true", help="do not sample rocm-smi during the timed steps (the sampler forks a subprocess every 1.5 s; "
@@ -428,8 +425,6 @@ def main():
         eng.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.gemm_tail_split >= 0:
         eng.set_option("gemm_tail_split", args.gemm_tail_split)
-    if args.dec_attn_variant >= 0:
-        eng.set_option("dec_attn_variant", args.dec_attn_variant)
     if args.prune_last >= 0:
         eng.set_option("prefill_prune_last", args.prune_last)
     if args.fused_reduce >= 0:
@@ -438,8 +433,6 @@ def main():
         eng.set_option("gemm_nt_out", args.gemm_nt_out)
     if args.dec_attn_pps > 0:
         eng.set_option("dec_attn_pps", args.dec_attn_pps)
-    if args.attn_fused_combine >= 0:
-        eng.set_option("dec_attn_fused_combine", args.attn_fused_combine)
 
     # synthetic inputs, resident in HBM before the timed region.  Clip i of the job's world * B clips belongs to rank i % world - the
     # reference harness's round-robin `islice(docs, rank, None, world_size)` (lmms_eval/utils.py:675-681, aurora_amd.parallel.shard_clips).
@@ -1035,9 +1028,8 @@ def main():
             mean_ctx = L0 + N / 2.0
             alg = B * mean_ctx * 2 * d * 2                               # K + V bytes (q and the split partials are < 0.1 %)
             avg_s = ams / an * 1e-3
-            att_pmc = pmc_of("decode_attn_dot_kernel") or pmc_of("decode_attn_pipe_kernel")
-            roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_dot_kernel<4, 8> (paged decode attention, v_dot2c page pipeline)" if args.dec_attn_variant in (-1, 4)
-                                   else "decode_attn_pipe_kernel<4, 8> (paged decode attention, MFMA page pipeline)",
+            att_pmc = pmc_of("decode_attn_dot_kernel")
+            roof["decode_attn"] = {"bound": "hbm", "kernel": "decode_attn_dot_kernel<4, 8> (paged decode attention, v_dot2c page pipeline)",
                                    "achieved": alg / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / avg_s / 8e12,
                                    # HBM bytes per launch from the PMC counters, UNSCALED, at the counter pass's own context (the pass decodes
                                    # 6 tokens after the same prefill: B x 2145 cached tokens), with the algorithmic bytes at that context beside it

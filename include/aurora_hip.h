@@ -208,17 +208,15 @@ int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size,
 /* Copy the last-position logits of the most recent prefill / decode step into dst_dev: fp32 [batch, vocab]. */
 int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 
-/* Tuning knobs (invalidate the captured decode graph): "dec_attn_variant" 4 (default: v_dot2c page pipeline) / 1 (MFMA page pipeline) /
- * 3 (the same with two waves per SIMD) / 2 (default-policy K / V loads) / 0 (un-pipelined), "decode_fused_reduce" 0 (default: the split-K
- * residual projections are followed by a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same),
- * "dec_attn_fused_combine" 0 (default: decode_attn_combine_kernel follows the split attention as its own launch) / 1 (the last-arriving
- * split of a (sequence, head) combines in the attention kernel; bitwise the same, 0.3 % slower on 8-slot engines: DESIGN section 10),
+/* Tuning knobs (invalidate the captured decode graph): "decode_fused_reduce" 0 (default: the split-K residual projections are followed by
+ * a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same), "tome_fused_ln" 1 (default: LayerNorm 2 of a
+ * merging ViT layer comes out of the ToMe merge launch) / 0 (its own launch; bitwise the same),
  * "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_nt_out" -1 (default: GEMM outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
- * LDS; the default above 32 slots), "skinny_row_split_min_k", "skinny_ring", "gemm_tile_order" 1 (rounds of the persistent grid are
+ * LDS; the default above 32 slots), "skinny_row_split_min_k", "gemm_tile_order" 1 (rounds of the persistent grid are
  * compact tile blocks shared by the XCDs) / 0 (per-XCD tile ranges), "gemm_tail_split" 1 (a mostly idle last round of the 256x256
  * kernel goes to the 128x128 kernel over the bottom rows) / 0, "microbench_prefill_nseq" sequences per pass for the pre_*
  * microbenchmarks.  "decode_half_grid" 1 / 0 does NOT invalidate the graphs (one is kept per setting): the next aur_llm_decode

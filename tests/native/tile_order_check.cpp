@@ -35,39 +35,6 @@ int main() {
                 }
                 ++checked;
             }
-    // mode 2 (hand-down): bijection, an XCD keeps its band of 4 M-tiles through a super-row, and the column group XCD x works on in
-    // round rho is the one XCD x - 1 worked on in round rho - 1
-    for (int G : grids)
-        for (int nbm = 1; nbm <= 100; nbm += (nbm < 20 ? 1 : 3))
-            for (int nbn = 1; nbn <= 90; nbn += (nbn < 20 ? 1 : 7)) {
-                TileOrder o;
-                tile_order_init(o, nbm, nbn, G, 2);
-                std::vector<int> seen(nbm * nbn, 0);
-                for (int bid = 0; bid < nbm * nbn; ++bid) {
-                    int bm = -1, bn = -1;
-                    tile_of_bid(o, bid, bm, bn);
-                    if (bm < 0 || bm >= nbm || bn < 0 || bn >= nbn || seen[bm * nbn + bn]++) {
-                        printf("FAIL mode 2 G=%d nbm=%d nbn=%d bid=%d -> (%d, %d)\n", G, nbm, nbn, bid, bm, bn);
-                        return 1;
-                    }
-                    if (bid < o.full) {
-                        const int rnd = bid / G, sr = rnd / o.nfn, xcd = bid & 7;
-                        if (bm < sr * 32 + xcd * 4 || bm >= sr * 32 + xcd * 4 + 4) {
-                            printf("FAIL mode 2 band G=%d nbm=%d nbn=%d bid=%d\n", G, nbm, nbn, bid);
-                            return 1;
-                        }
-                        if (xcd > 0 && rnd % o.nfn > 0) {            // same position one XCD and one round earlier: same column
-                            int pm, pn;
-                            tile_of_bid(o, bid - G - 1, pm, pn);
-                            if (pn != bn) {
-                                printf("FAIL mode 2 hand-down G=%d nbm=%d nbn=%d bid=%d\n", G, nbm, nbn, bid);
-                                return 1;
-                            }
-                        }
-                    }
-                }
-                ++checked;
-            }
     printf("ok %ld shapes\n", checked);
     return 0;
 }

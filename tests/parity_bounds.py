@@ -14,8 +14,6 @@ LOGIT_TOL_WIDE = 3.5e-3
 LOGIT_TOL_DEEP = 2.5e-2
 # hidden states / features vs the fp32 oracle on identical merges, rel-L2.  Observed worst 6.5e-4 (G7 erf-GELU chain, free running)
 FEAT_TOL = 1.9e-3
-# two decode-attention kernels of different summation order against each other, relative to max |logit|.  Observed 4.3e-4
-VARIANT_TOL = 1.2e-3
 # the two decode-projection structures (x per wave / x through LDS) against each other.  Observed 2.0e-4
 STRUCTURE_TOL = 6e-4
 # an index difference against the fp32 oracle / the reference-held arrays must be a near tie of the fp32 scores: largest gap

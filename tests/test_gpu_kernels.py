@@ -315,11 +315,10 @@ def test_gemm_tile_orders_agree_bitwise(eng):
         eng.set_option("gemm_mode", 1)
 
 
-def test_tome_match_hand_over_stress_alone_and_beside_a_decode_stream():
-    """The match -> select hand-over of tome_match_kernel (per-frame arrival counter, `sc1` payload, drained vmcnt, `sc1` loads in
-    the last workgroup - not a HIP-memory-model release/acquire pair: ADVICE r2) under the conditions that expose a stale read:
-    many frames (uneven arrival: 64 frames x 12 workgroups over 256 CUs), many layers' worth of shapes, repeated, and the same next
-    to a bandwidth-hungry stream on the other CUs.  Every run must reproduce the C oracle's indices bit for bit."""
+def test_tome_indices_under_stress_alone_and_beside_a_decode_stream():
+    """Rounds 2-4 ranked a frame in the LAST workgroup of the match launch to arrive (agent-scope hand-over) and this test hunted for a lost
+    or early hand-over.  Round 5 removed the hand-over (match -> select -> merge are separate launches); the stress stays as a race screen
+    of the four-launch step: many frames, ragged shapes, repeated, alone and beside a busy stream - bit-equal to the C oracle every time."""
     from aurora_amd.engine import AuroraCapEngine
     cfg = {"vit": dict(hidden_size=1280, num_attention_heads=16, num_hidden_layers=2, intermediate_size=256, patch_size=14,
                        image_size=378, hidden_act="quick_gelu"), "llm": None}
@@ -358,14 +357,11 @@ def test_tome_match_hand_over_stress_alone_and_beside_a_decode_stream():
         eng.close()
 
 
-def test_tome_hand_over_beside_the_real_decode_graph_on_cu_masked_streams():
-    """ADVICE r3 (medium) / VERDICT r3 item 2: the ToMe match -> select hand-over stressed in the SERVING arrangement, not beside a
-    synthetic `add_`: the ViT-H encoder (31 ToMe steps per pass, 32 frames) runs on the front-end stream (16 CUs of every XCD) while the
-    captured decode step of a 128-slot engine (real widths: K / V stream of 128 x 2.1k tokens, 4096-wide projections) replays on the
-    other 16.  `hidden_states[-2]` depends on every layer's indices bit for bit, so one stale read in ~16 k hand-overs (16 passes x 31
-    layers x 32 frames) would change the features: every pass must equal the pass taken alone.
-    (Round 3's fused split-K reduce failed in exactly this arrangement; its cause was an unpadded inline-asm store hazard, not the
-    arrival protocol - profiles/r04_fused_reduce_rootcause.txt - and tome_match_kernel's stores are compiler-emitted.)"""
+def test_tome_beside_the_real_decode_graph_on_cu_masked_streams():
+    """The ToMe step stressed in the SERVING arrangement (ADVICE r3 / VERDICT r3 item 2; since round 5 the step has no cross-workgroup
+    hand-over left, the test stays as the race screen of the front end beside the decode graph): 16 ViT-H passes of 32 frames on the
+    front-end CU mask while a 128-slot decode graph replays on the other 16 CUs of every XCD.  `hidden_states[-2]` depends on every
+    layer's indices bit for bit, so one wrong index in ~16 k ToMe steps shows: every pass must be bit-equal to the pass alone."""
     from aurora_amd import synthetic as S
     from aurora_amd.engine import AuroraCapEngine, _rup
     from aurora_amd.streams import shared_cu_masked_stream

@@ -26,7 +26,7 @@ LLM_CFGS_VOCAB = {
     "v9000": dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=256, vocab_size=9000,
                   rms_norm_eps=1e-5, rope_theta=1e4, rope_factor=1.0),
 }
-from tests.parity_bounds import FEAT_TOL, LOGIT_TOL, VARIANT_TOL  # noqa: E402  (max-abs relative to max |logit|; frozen from the observed errors)
+from tests.parity_bounds import FEAT_TOL, LOGIT_TOL  # noqa: E402  (max-abs relative to max |logit|; frozen from the observed errors)
 
 
 def make_engine(cfg, seed, max_batch=2, use_graph=True, max_ctx=512, max_new=24):
@@ -274,40 +274,12 @@ def test_single_split_decode_attention_finishes_in_the_kernel(name):
     assert outs[False] == outs[True]
 
 
-def test_decode_attention_variants_are_bitwise_equal():
-    """dec_attn_variant 3 (K re-loaded into the same registers once the Q K^T products of a page are issued: two waves per SIMD,
-    twice the loads in flight per CU) performs the operations of variant 1 in the same order: logits and ids must be bitwise
-    equal, single split (large batch) and multi-split (batch 1) alike, head_dim 128."""
-    cfg = LLM_CFGS["hd128"]
-    for batch, ctx in ((1, 700), (3, 300)):
-        eng, w = make_engine(cfg, 21, max_batch=batch, use_graph=False, max_ctx=1024, max_new=12)
-        try:
-            gen = torch.Generator().manual_seed(40 + batch)
-            embs = [torch.randn(ctx - 17 * b, cfg["hidden_size"], generator=gen).half().float() for b in range(batch)]
-            outs = {}
-            for variant in (1, 3, 0):
-                eng.set_option("dec_attn_variant", variant)
-                eng.begin_batch(batch, 12, None)
-                for b in range(batch):
-                    eng.prefill(b, padded(embs[b]), embs[b].shape[0])
-                logits = []
-                for _ in range(6):
-                    eng.decode(1)
-                    logits.append(eng.logits().clone())
-                outs[variant] = (eng.outputs(), torch.stack(logits))
-            assert outs[1][0] == outs[3][0]
-            assert torch.equal(outs[1][1], outs[3][1])
-            assert outs[0][0] == outs[1][0]                  # the un-pipelined kernel: same order too
-        finally:
-            eng.close()
-
-
 @pytest.mark.parametrize("name", ["hd32", "hd128"])
-def test_decode_attention_on_the_valu_matches_the_mfma_form(name):
-    """dec_attn_variant 4 computes the decode attention with v_dot2c_f32_f16 instead of MFMAs whose 16 columns all hold the same
-    query (15 / 16 of the products wasted - watts, on a path that runs at the socket power cap).  Different summation order, so
-    not bitwise the MFMA form: logits within 2e-3 of the logit scale of variant 1 and within the kernel tolerance of the fp32
-    oracle, tokens equal wherever the oracle's margin is clear; deterministic; batched == single; graph == eager."""
+def test_decode_attention_against_the_oracle_split_counts_graph_and_batch(name):
+    """The decode attention (v_dot2c page pipeline, decode.hip; the MFMA forms of rounds 1-4 are gone) at head_dim 32 and 128: several
+    splits per (sequence, head) + decode_attn_combine_kernel (batch 1) and one split (batch 3), and forced split counts
+    (`dec_attn_pps` 1 / 2 / 4 pages per split: another summation order each, so not bitwise equal to one another): logits within
+    the kernel tolerance of the fp32 oracle, bitwise repeatable; batched == single; graph == eager."""
     cfg = LLM_CFGS[name]
     ref = {}
     for batch, ctx in ((1, 700), (3, 300)):
@@ -316,8 +288,9 @@ def test_decode_attention_on_the_valu_matches_the_mfma_form(name):
             gen = torch.Generator().manual_seed(40 + batch)
             embs = [torch.randn(ctx - 17 * b, cfg["hidden_size"], generator=gen).half().float() for b in range(batch)]
             outs = {}
-            for variant in (1, 4, 4):
-                eng.set_option("dec_attn_variant", variant)
+            for pps in (0, 0, 1, 2, 4):                      # 0 = the engine's own choice, run twice: bitwise repeatable
+                if pps:
+                    eng.set_option("dec_attn_pps", pps)
                 eng.begin_batch(batch, 12, None)
                 for b in range(batch):
                     eng.prefill(b, padded(embs[b]), embs[b].shape[0])
@@ -326,23 +299,20 @@ def test_decode_attention_on_the_valu_matches_the_mfma_form(name):
                     eng.decode(1)
                     logits.append(eng.logits().clone())
                 cur = (eng.outputs(), torch.stack(logits))
-                if variant in outs:                          # second run of variant 4: bitwise repeatable
-                    assert cur[0] == outs[variant][0] and torch.equal(cur[1], outs[variant][1])
-                outs[variant] = cur
-            scale = outs[1][1].abs().max().item()
-            observe("llm/dec_attn_valu_vs_mfma_logits_over_scale", (outs[1][1] - outs[4][1]).abs().max().item() / scale, VARIANT_TOL)
-            # against the oracle: teacher-forced logits of the tokens variant 4 produced, slot 0
-            ids = outs[4][0][0]
-            want = teacher_forced_logits(embs[0], ids[:7], w, cfg)
-            got = outs[4][1][:, 0].float().cpu()
-            observe("llm/dec_attn_variants_logits_max_err_over_scale", (got - want[1:7]).abs().max().item() / want.abs().max().item(), LOGIT_TOL)
-            ref[batch] = (embs, outs[4])
+                if pps in outs:
+                    assert cur[0] == outs[pps][0] and torch.equal(cur[1], outs[pps][1])
+                outs[pps] = cur
+                # against the oracle: teacher-forced logits of the tokens this run produced, slot 0
+                ids = cur[0][0]
+                want = teacher_forced_logits(embs[0], ids[:7], w, cfg)
+                got = cur[1][:, 0].float().cpu()
+                observe("llm/dec_attn_split_counts_logits_max_err_over_scale", (got - want[1:7]).abs().max().item() / want.abs().max().item(), LOGIT_TOL)
+            ref[batch] = (embs, outs[0])
         finally:
             eng.close()
-    # graph replay == eager launches, and a batch == its sequences alone, with the VALU form
+    # graph replay == eager launches, and a batch == its sequences alone
     eng, w = make_engine(cfg, 21, max_batch=3, use_graph=True, max_ctx=1024, max_new=12)
     try:
-        eng.set_option("dec_attn_variant", 4)
         embs, (ids3, _) = ref[3]
         eng.begin_batch(3, 12, None)
         for b in range(3):
@@ -396,44 +366,3 @@ def test_pruned_last_prefill_layer_is_bitwise_the_full_one(name, L, nseq):
         eng.close()
 
 
-@pytest.mark.parametrize("name,batch,ctx", [("hd128", 1, 900), ("hd128", 3, 500), ("hd64", 2, 300), ("hd32", 1, 200)])
-def test_in_kernel_attention_combine_is_bitwise_the_combine_kernel(name, batch, ctx):
-    """Engines whose batch alone does not fill the GPU run several splits per (sequence, head); since round 4 the split that finds
-    its pair complete (agent-scope arrival counter, write-through partials, sc1 loads) combines them IN decode_attn_dot_kernel, in the
-    fixed split order and with the same function as decode_attn_combine_kernel - whose launch disappears (32 of 225 per 8-slot step).
-    Same additions in the same order: ids and logits bit for bit, eager and as a hipGraph, repeated (a lost or early hand-over
-    would show as a different sum) with a second stream keeping the GPU busy, ragged contexts so that splits finish unevenly; the
-    arrival counters are back at zero after every launch (graph replays rely on it)."""
-    cfg = LLM_CFGS[name]
-    gen = torch.Generator().manual_seed(500 + batch)
-    lens = [ctx - 37 * b for b in range(batch)]
-    embs = [torch.randn(L, cfg["hidden_size"], generator=gen).half().float() for L in lens]
-    res = {}
-    for use_graph in (False, True):
-        eng, w = make_engine(cfg, 23, max_batch=batch, use_graph=use_graph, max_ctx=1024, max_new=16)
-        try:
-            noise = torch.randn(4096, 4096, device="cuda")
-            side = torch.cuda.Stream()
-            for fused in (0, 1, 1):
-                eng.set_option("dec_attn_fused_combine", fused)
-                with torch.cuda.stream(side):                      # a busy neighbour: uneven arrival of the splits
-                    for _ in range(20):
-                        noise = noise @ noise * 1e-4
-                eng.begin_batch(batch, 16, None)
-                for b in range(batch):
-                    eng.prefill(b, padded(embs[b]), lens[b])
-                logits = []
-                for _ in range(10):
-                    eng.decode(1)
-                    logits.append(eng.logits().clone())
-                cur = (eng.outputs(), torch.stack(logits))
-                side.synchronize()
-                if (use_graph, fused) in res:
-                    assert cur[0] == res[(use_graph, fused)][0] and torch.equal(cur[1], res[(use_graph, fused)][1])
-                res[(use_graph, fused)] = cur
-        finally:
-            eng.close()
-    base = res[(False, 0)]
-    for key, cur in res.items():
-        assert cur[0] == base[0], key
-        assert torch.equal(cur[1], base[1]), key

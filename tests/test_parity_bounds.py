@@ -47,7 +47,7 @@ def test_every_bound_is_within_three_times_the_observed_worst(rec):
 def test_the_named_constants_are_the_recorded_ones(rec):
     want = {"llm/batched_logits_max_err_over_scale": P.LOGIT_TOL, "configs/llama7b_width_2_layers_logits_over_scale": P.LOGIT_TOL_WIDE,
             "configs/llama7b_full_depth_logits_over_scale": P.LOGIT_TOL_DEEP, "configs/vit_h_every_layer_teacher_forced_rel_l2": P.FEAT_TOL,
-            "llm/dec_attn_valu_vs_mfma_logits_over_scale": P.VARIANT_TOL, "skinny_lds/structure_0_vs_1_logits_over_scale": P.STRUCTURE_TOL,
+            "skinny_lds/structure_0_vs_1_logits_over_scale": P.STRUCTURE_TOL,
             "golden/g7_mid_flip_boundary_gap": P.NEAR_TIE, "golden/g7_mid_frame_layers_with_reference_indices": P.G7_MID_AGREE,
             "configs/vit_h_free_run_agreeing_frame_layers": P.FREE_RUN_AGREE, "configs/vit_h_free_run_mean_feature_drift": P.FREE_RUN_DRIFT}
     for key, const in want.items():

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from aurora_amd import synthetic as S                     # noqa: E402
 from aurora_amd.engine import AuroraCapEngine, _rup       # noqa: E402
 from aurora_amd.streams import cu_masked_stream           # noqa: E402
-from tools.cumask.contention_lab import clock_probe_lib   # noqa: E402
+from tools.cumask.clock_probe import clock_probe_lib   # noqa: E402
 
 
 def main():

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from aurora_amd.streams import cu_masked_stream           # noqa: E402
-from tools.cumask.contention_lab import clock_probe_lib   # noqa: E402
+from tools.cumask.clock_probe import clock_probe_lib   # noqa: E402
 
 
 def main():

@@ -76,22 +76,17 @@ def main():
         eng.set_option("skinny_variant", variant)
         run(tag, dec)
     eng.set_option("skinny_variant", 1)
-    if B > 64:
-        eng.set_option("skinny_ring", 1)
-        run("x-through-LDS ring 2 x 8", ["dec_qkv", "dec_gateup"])
-        eng.set_option("skinny_ring", 0)
     eng.set_option("skinny_variant", 1 if B > 32 else 0)
     if not args.quick:
         for nw in (4, 8):
             eng.set_option("dec_row_waves", nw)
             run(f"row kernels {nw} waves", ["dec_o", "dec_down"])
-        for variant in (0, 1):
-            eng.set_option("dec_attn_variant", variant)
-            for pps in (1, 2, 4, 8):
-                eng.set_option("dec_attn_pps", pps)
-                run(f"attn v{variant} pps{pps}", ["dec_attn"])
+        run("attn (engine's splits)", ["dec_attn"])
+        for pps in (1, 2, 4, 8, 19, 38):
+            eng.set_option("dec_attn_pps", pps)
+            run(f"attn pps{pps}", ["dec_attn"])
     else:
-        run("attn v1 pps4", ["dec_attn"])
+        run("attn (engine's splits)", ["dec_attn"])
     for mode, wide, tag in ((0, 1, "prefill gemm128"), (2, 0, "prefill gemm256 direct stores"), (2, 1, "prefill gemm256 LDS epilogue")):
         eng.set_option("gemm_mode", mode)
         eng.set_option("gemm_wide_epilogue", wide)
@@ -101,11 +96,6 @@ def main():
         for v in (0, 1, 0, 1):
             eng.set_option(args.ab_option, v)
             run(f"{args.ab_option} = {v}", ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
-    if not args.quick:
-        eng.set_option("dec_attn_variant", 1)
-        for pps in (19, 38, 64):
-            eng.set_option("dec_attn_pps", pps)
-            run(f"attn v1 pps{pps}", ["dec_attn"])
     run("prefill", ["pre_norm", "pre_attn"])
     print(json.dumps(res))
     eng.close()
