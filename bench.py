@@ -115,7 +115,8 @@ def parse():
     p.add_argument("--batch-mode", action="store_true",
                    help="time K independent batches (front end of all B clips, then B-wide decode) instead of the default steady-state "
                         "continuous batching (same work per step, first tokens ~5x later)")
-    p.add_argument("--no-latency-point", action="store_true", help="(kept for old command lines; the continuous mode is the default now)")
+    p.add_argument("--no-latency-point", action="store_true", help="skip the latency-first point of the frontier (prefill groups of 2, one timed cycle in a child "
+                   "process after the timed steps of the default cfg2 run)")
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
     p.add_argument("--tiny-deep", action="store_true", help="host-side rehearsal: tiny widths but the REAL layer counts (31 ViT + 32 Llama layers), so that a cycle "
                    "enqueues the real number of launches with kernels of a few microseconds - what the host of an 8-rank node has to sustain (`host` in the line)")
@@ -321,7 +322,7 @@ def self_launch(n: int) -> int:
 def child_point(flags, timeout=1200):
     """One more operating point of this benchmark in a child process (its own engine); -> the child's JSON line, or None."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--no-cpu-baseline", "--no-power", "--no-single-stream"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--no-cpu-baseline", "--no-power", "--no-single-stream", "--no-latency-point"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
         lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -1191,8 +1192,10 @@ def main():
                 "ideal_tokens_per_s": ds.get("ideal_tokens_per_s"), "frac": ds.get("frac"), "bound": "hbm",
                 "how": "`python bench.py --batch 1` in a child process (one KV slot, hipGraph decode, 2 timed captions); frac = (13.21 GB of weights + "
                        "K / V of the mean context) / 8 TB/s over the measured decode step"})
-        if args.frontier:
-            for g_ in (1, 2, 8):
+        # the latency-first operating point (groups of 2: half the TTFT for ~6 % of the throughput) is measured in every default run;
+        # --frontier adds groups of 1 and 8
+        for g_ in ((2,) if not args.no_latency_point else ()) + ((1, 8) if args.frontier else ()):
+            if True:
                 if g_ == G:
                     continue
                 c = child_point(["--prefill-group", str(g_), "--steps", "1", "--warmup", "1", "--no-instrument"])

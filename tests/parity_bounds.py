@@ -11,11 +11,11 @@ LOGIT_TOL = 2e-3
 # the same at Llama-7B WIDTH (4096 / 11008 / 32000) and 2 layers over a 300-row prefix: longer dot products.  Observed 1.23e-3
 LOGIT_TOL_WIDE = 3.5e-3
 # the same at Llama-7B width AND depth (32 layers: 64 fp16 roundings of the residual stream, each 2^-11 relative).  Observed 8.3e-3
-LOGIT_TOL_DEEP = 2.5e-2
+LOGIT_TOL_DEEP = 2.4e-2
 # hidden states / features vs the fp32 oracle on identical merges, rel-L2.  Observed worst 6.5e-4 (G7 erf-GELU chain, free running)
 FEAT_TOL = 1.9e-3
 # the two decode-projection structures (x per wave / x through LDS) against each other.  Observed 2.0e-4
-STRUCTURE_TOL = 6e-4
+STRUCTURE_TOL = 5.9e-4
 # an index difference against the fp32 oracle / the reference-held arrays must be a near tie of the fp32 scores: largest gap
 # accepted.  Observed worst 1.2e-4 (G7 mid, r boundary), 3.9e-5 (ViT-H free run)
 NEAR_TIE = 3.6e-4
