@@ -66,6 +66,71 @@ __global__ __launch_bounds__(512) void proj_kernel(const half_t* W, int64_t frag
     }
 }
 
+// variant 4 ("run-ahead"): projection k + 1 is launched on a SECOND stream while projection k runs; its waves request their first U
+// fragments at once and only then wait for projection k's completion count (what its x operand would depend on); every workgroup
+// counts itself in when it is done (release fence + agent-scope add).  Spins are bounded: a chain that the runtime serialises in the
+// wrong order gives up and raises `err` instead of hanging the GPU.
+template <int U>
+__global__ __launch_bounds__(512) void proj_ra_kernel(const half_t* W, int64_t frags, const unsigned* wait_cnt, unsigned expected, unsigned* signal_cnt,
+                                                      unsigned* err, float* out) {
+    __shared__ float red[512];
+    __shared__ int ok;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 8;
+    const int64_t per = frags / nwave;
+    const half_t* p = W + wave * per * 512 + lane * 8;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    h8 xc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xc[j] = (half_t)(0.001f * (lane + j));
+    h8 t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = __builtin_nontemporal_load((const h8*)(p + (u < per ? u : per - 1) * 512));      // run ahead of the dependency
+    if (threadIdx.x == 0) {
+        int good = 1;
+        if (wait_cnt) {
+            long spins = 0;
+            while (__hip_atomic_load(wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 400000) { good = 0; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) {
+        if (threadIdx.x == 0) atomicAdd(err, 1u);
+    }
+    for (int64_t i = 0; i < per; i += U) {
+        h8 n[U];
+        const bool more = i + U < per;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) n[u] = __builtin_nontemporal_load((const h8*)(p + ((i + U + u) < per ? (i + U + u) : per - 1) * 512));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(t[u], xc, acc);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = n[u];
+        }
+    }
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[w * 64 + threadIdx.x];
+        out[1 + blockIdx.x * 64 + threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(signal_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // side-branch prefetcher: `wgs` workgroups of 256 threads touch one dword per 128-byte line of [p, p + bytes)
 __global__ __launch_bounds__(256) void touch_kernel(const char* p, int64_t bytes, float* out) {
     const int64_t lines = bytes / 128;
@@ -157,6 +222,65 @@ int main(int argc, char** argv) {
         CKH(hipGraphDestroy(g));
         for (auto e : evs) CKH(hipEventDestroy(e));
     };
+    // ---- run-ahead chain: projections alternate between two streams, ordered by completion counters only
+    unsigned* cnt;
+    CKH(hipMalloc(&cnt, (chain.size() + 2) * sizeof(unsigned)));
+    unsigned* errp = cnt + chain.size() + 1;
+    auto run_ra = [&](const char* tag, bool graph, bool two_streams) {
+        hipStream_t ss[2] = {st, two_streams ? side : st};
+        auto enqueue = [&](unsigned epoch) {
+            for (size_t k = 0; k < chain.size(); ++k)
+                proj_ra_kernel<8><<<256, 512, 0, ss[k & 1]>>>((const half_t*)chain[k].w, chain[k].frags, k ? cnt + (k - 1) : nullptr, 256u * epoch, cnt + k, errp, out);
+        };
+        CKH(hipMemset(cnt, 0, (chain.size() + 2) * sizeof(unsigned)));
+        CKH(hipDeviceSynchronize());
+        unsigned epoch = 0;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        hipEvent_t a, b, fk, jn;
+        CKH(hipEventCreate(&a)); CKH(hipEventCreate(&b));
+        CKH(hipEventCreateWithFlags(&fk, hipEventDisableTiming)); CKH(hipEventCreateWithFlags(&jn, hipEventDisableTiming));
+        // the expected counts grow with every replay, so a captured graph (fixed arguments) only serves ONE epoch: capture per replay is not
+        // what an engine would do - it would keep the epoch in device memory.  For the lab: eager launches on two streams measure the
+        // overlap itself; the graph case re-zeroes the counters with a memset node in front of the chain instead.
+        if (graph) {
+            CKH(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            CKH(hipMemsetAsync(cnt, 0, (chain.size() + 1) * sizeof(unsigned), st));
+            if (two_streams) { CKH(hipEventRecord(fk, st)); CKH(hipStreamWaitEvent(side, fk, 0)); }
+            enqueue(1);
+            if (two_streams) { CKH(hipEventRecord(jn, side)); CKH(hipStreamWaitEvent(st, jn, 0)); }
+            CKH(hipStreamEndCapture(st, &g));
+            CKH(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        }
+        auto once = [&]() {
+            if (graph) { CKH(hipGraphLaunch(ge, st)); return; }
+            ++epoch;
+            if (two_streams) { CKH(hipEventRecord(fk, st)); CKH(hipStreamWaitEvent(side, fk, 0)); }
+            enqueue(epoch);
+            if (two_streams) { CKH(hipEventRecord(jn, side)); CKH(hipStreamWaitEvent(st, jn, 0)); }
+        };
+        for (int i = 0; i < 2; ++i) once();
+        CKH(hipStreamSynchronize(st));
+        CKH(hipEventRecord(a, st));
+        for (int i = 0; i < reps; ++i) once();
+        CKH(hipEventRecord(b, st));
+        CKH(hipStreamSynchronize(st));
+        float ms;
+        CKH(hipEventElapsedTime(&ms, a, b));
+        unsigned herr = 0;
+        CKH(hipMemcpy(&herr, errp, sizeof(unsigned), hipMemcpyDeviceToHost));
+        const double us_layer = 1e3 * ms / reps / layers;
+        printf("%-64s %8.2f us/layer  %6.2f TB/s   give-ups %u\n", tag, us_layer, layer_bytes / us_layer / 1e6, herr);
+        fflush(stdout);
+        if (ge) CKH(hipGraphExecDestroy(ge));
+        if (g) CKH(hipGraphDestroy(g));
+    };
+    run_ra("4 counters only, ONE stream, eager (no overlap possible)", false, false);
+    run_ra("4 run-ahead, two streams, eager", false, true);
+    run_ra("4 counters only, ONE stream, graph", true, false);
+    run_ra("4 run-ahead, two streams, graph", true, true);
+    run_ra("4 run-ahead, two streams, eager (again)", false, true);
+
     // per-projection alone (eager, back to back): the launch-form floor of each shape
     for (int i = 0; i < 4; ++i) {
         hipEvent_t a, b;
