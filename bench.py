@@ -1003,7 +1003,7 @@ def main():
         how = "HIP events around every launch of this kernel in one extra eager, un-pipelined step on the launch stream (after the timed steps)"
         # rocprofv3 --pmc summary of this same command (tools/profile_round.sh -> profiles/r02_pmc.json), if committed: per-kernel
         # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE KiB, separate passes) measured at 6 new tokens, scaled to this run below
-        pmc, pmc_ctx, pmc_tag, pmc_build = {}, None, "r02", None
+        pmc, pmc_ctx, pmc_tag, pmc_build, pmc_all = {}, None, "r02", None, []
         try:
             pj = None
             for tag in ("r05", "r04", "r03", "r02"):                   # the newest committed counter summary
@@ -1015,6 +1015,7 @@ def main():
             pmc_build = (pj.get("_build") or {}).get("lib_sha16")
             for ent in pj["kernels"]:
                 if "hbm_bytes_per_launch" in ent:
+                    pmc_all.append(ent)
                     pmc.setdefault(ent["kernel"].split("(")[0].replace("void ", ""), ent)
         except Exception:
             pass
@@ -1142,15 +1143,25 @@ def main():
                     tb_ += 2.0 * (tt_ * hdv_ + tt_ * v["hidden_size"] + (tt_ - rl_) * v["hidden_size"]) + 4.0 * (2 * tt_ - rl_)
                 tt_ -= rl_
             tome_bytes_clip = F * tb_
-            tome_pmc = [pmc_of(k) for k in ("tome_prep_kernel", "tome_match_kernel", "tome_select_kernel", "tome_merge_kernel")]
+            # the counter file holds one entry per (kernel, grid): the LARGEST grid of each ToMe kernel is the first layer (t = t0) of the pass
+            tome_pmc = [max((e for e in pmc_all if k in e["kernel"]), key=lambda e: e.get("grid", 0), default=None)
+                        for k in ("tome_prep_kernel", "tome_match_kernel", "tome_select_kernel", "tome_merge_kernel")]
             tome_traffic = sum(e["hbm_bytes_per_launch"] for e in tome_pmc) if all(tome_pmc) else None
             sv_clips = min(VC, B)
+            rl0 = min(r, (t0tok - 1) // 2)
+            tome_alg_l0 = sv_clips * F * (2.0 * (t0tok * hdv_ + t0tok * v["hidden_size"] + (t0tok - rl0) * v["hidden_size"]) + 4.0 * (2 * t0tok - rl0))
             result["roofline_tome"] = {
                 "bound": "hbm", "kernel": "tome_prep / tome_match (v_mfma_f32_16x16x4_f32) / tome_select / tome_merge (+ LayerNorm 2), four launches per layer",
                 "achieved": (B * tome_bytes_clip / (tome_ms_batch * 1e-3) / 1e9) if tome_ms_batch > 0 else None, "peak": 8000.0, "unit": "GB/s",
                 "frac": (B * tome_bytes_clip / (tome_ms_batch * 1e-3) / 8e12) if tome_ms_batch > 0 else None,
-                "traffic": tome_traffic, "traffic_note": "sum of the four launches' (2*FETCH_SIZE + WRITE_SIZE) KiB per layer-launch in profiles/%s_pmc.json, at %d "
-                                                         "frames per launch; null until a counter pass of this build is committed" % (pmc_tag, G * F),
+                "traffic": tome_traffic,
+                "traffic_context": {"layer": "first (t = %d -> %d)" % (t0tok, t0tok - rl0), "frames_per_launch": sv_clips * F,
+                                    "algorithmic_bytes_of_that_layer_launch": tome_alg_l0,
+                                    "traffic_over_algorithmic": (tome_traffic / tome_alg_l0) if tome_traffic else None},
+                "traffic_note": "sum over the four launches of the FIRST layer of (2*FETCH_SIZE + WRITE_SIZE) KiB in profiles/%s_pmc.json (%d frames per "
+                                "launch; counters taken on library build %s, this run loaded %s).  Above the SURVEY 8d bytes by what the formula does not count: "
+                                "prep reads the layer's K fragments of ALL heads to form the metric (16x the metric's own bytes) and merge also "
+                                "writes the LayerNorm 2 rows" % (pmc_tag, sv_clips * F, pmc_build, lib_sha),
                 "algorithmic_bytes_per_clip": tome_bytes_clip, "algorithmic_bytes_per_layer_launch_mean": sv_clips * tome_bytes_clip / max(v["num_hidden_layers"] - 1, 1),
                 "ms_per_clip": (tome_ms_batch / B) if tome_ms_batch > 0 else None, "frames_per_launch": sv_clips * F,
                 "single_clip": {"ms": st1["vit_tome"], "achieved": tome_bytes_clip / (st1["vit_tome"] * 1e-3) / 1e9 if st1["vit_tome"] > 0 else None,
