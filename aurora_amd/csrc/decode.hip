@@ -971,23 +971,23 @@ __device__ __forceinline__ void attn_combine_feature(const DecAttnArgs& a, int b
     const int64_t p0 = ((int64_t)b * a.heads + head) * a.nsplit;
     float M = -INFINITY;
     float num = 0.f, den = 0.f;
-    if (a.nsplit <= 32) {
-        // the engine's split counts (<= 16; <= 32 with --dec-attn-pps): every partial is fetched before the first is used - 3 x nsplit independent loads, one round
+    if (a.nsplit <= 16) {
+        // the engine's split counts (<= 16; a 32-wide version of this path cost 1.7 us per launch in registers and scalar spills): every partial is fetched before the first is used - 3 x nsplit independent loads, one round
         // trip - then the same operations in the same order as the loop below (rounds 1-4 ran that loop for every count: 2 x nsplit
         // DEPENDENT round trips, 6.4 us per launch at one slot where the attention itself takes 8.9 us)
-        float m[32], l[32], o[32];
+        float m[16], l[16], o[16];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < 16; ++s) {
             const int sc = s < a.nsplit ? s : a.nsplit - 1;
             m[s] = attn_part_ld(a.part_ml + (p0 + sc) * 2);
             l[s] = attn_part_ld(a.part_ml + (p0 + sc) * 2 + 1);
             o[s] = attn_part_ld(a.part_o + (p0 + sc) * a.hd + d);
         }
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = 0; s < 16; ++s)
             if (s < a.nsplit) M = fmaxf(M, m[s]);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < 16; ++s) {
             if (s >= a.nsplit || m[s] == -INFINITY) continue;
             const float wgt = __builtin_amdgcn_exp2f(m[s] - M);
             num = __builtin_fmaf(wgt, o[s], num);

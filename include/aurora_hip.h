@@ -180,7 +180,9 @@ int aur_slot_collect(aur_ctx* ctx, int32_t slot0, int32_t nslots, int32_t* ids_d
  * call site aurora.py:746-747).  metric fp32 [frames, t, c]; x fp16 [frames, t, d]; size fp32 [frames, t]
  * or NULL (= ones); x_out fp16 [frames, t-r', d]; size_out fp32 [frames, t-r'] with r' = min(r, (t-1)/2).
  * Optional index outputs (device int32, may be NULL): node_idx [frames, ceil(t/2)], unm_idx
- * [frames, ceil(t/2)-r'], src_idx [frames, r'], dst_idx [frames, r'].  r' <= 0: copies x/size. */
+ * [frames, ceil(t/2)-r'], src_idx [frames, r'], dst_idx [frames, r'].  r' <= 0: copies x/size.
+ * Limits: c <= 128 metric channels (the similarity runs on v_mfma_f32_16x16x4_f32 over operand blocks of 16 channels), ceil(t/2) <= 4096,
+ * d <= 2048 and a multiple of 8; anything else returns AUR_ERR_ARG. */
 int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, const float* size, int32_t frames,
                   int32_t t, int32_t c, int32_t d, int32_t r, void* x_out, float* size_out,
                   int32_t* node_idx, int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, void* stream);
@@ -223,7 +225,7 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * calls go to a stream that owns half of the CUs, so the QKV / gate-up projections launch half as many workgroups with twice the
  * tiles each - bitwise the same tokens.  "prefill_prune_last" 1 (default) / 0: the last layer of a prefill computes K / V for every
  * position and the rest for each sequence's last 128 rows only - nothing else is read after it; bitwise the same logits and K / V; no graph
- * is affected.  The gemm_* knobs (incl. "gemm_tile_order" 2, "gemm_lab" 0..7: lab variants, timing only) keep the graphs as well: no GEMM
+ * is affected.  The gemm_* knobs (incl. "gemm_lab": lab variants of AUR_LABS builds, timing only) keep the graphs as well: no GEMM
  * is part of the captured decode step.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;
  * the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
