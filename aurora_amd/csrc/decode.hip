@@ -1013,12 +1013,18 @@ __device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
     c = __builtin_amdgcn_fdot2(h2{a[6], a[7]}, h2{b[6], b[7]}, c, false);
     return c;
 }
-template <int KBLK, int VD16>
-__global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
-    __shared__ __attribute__((aligned(16))) half_t p16[64];
-    const int lane = threadIdx.x;
+// S = splits of a (sequence, head) that live in ONE workgroup (one wave each).  S == 1: a wave per workgroup; the splits of a pair are
+// separate workgroups and decode_attn_combine_kernel joins them.  S > 1 (engines whose batch x heads alone gives one workgroup per
+// CU, 8-15 slots of 32 heads: round 5): the workgroup holds ALL splits of its pair and joins them through LDS behind one barrier -
+// the same operations in the same order as the combine kernel (same bits), without its launch or the partials' round trip.
+template <int KBLK, int VD16, int S = 1>
+__global__ __launch_bounds__(64 * S, S == 1 ? 2 : 1) void decode_attn_dot_kernel(DecAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) half_t p16s[S][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = S == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    half_t* p16 = p16s[wv];
     const int g = lane >> 4, r = lane & 15;
-    const int sp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int sp = blockIdx.x * S + wv, head = blockIdx.y, b = blockIdx.z;
     const KvLayout& kv = a.kv;
     const int npos = a.pos[b] + 1;
     const int seq = a.seq_ids ? a.seq_ids[b] : b;
@@ -1112,6 +1118,33 @@ __global__ __launch_bounds__(64, 2) void decode_attn_dot_kernel(DecAttnArgs a) {
         acc_o[d] = xor16_sum(acc_o[d]);
         acc_o[d] = xor32_sum(acc_o[d]);
     }
+    if constexpr (S > 1) {
+        __shared__ float lo[S][VD16 * 16], lm[S], ll[S];
+#pragma unroll
+        for (int d = 0; d < VD16; ++d)
+            if ((d & 3) == g) lo[wv][d * 16 + r] = acc_o[d];
+        if (lane == 0) {
+            lm[wv] = m_run;
+            ll[wv] = l;
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < a.hd; d += 64 * S) {       // attn_combine_feature on the workgroup's own partials
+            float M = -INFINITY;
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) M = fmaxf(M, lm[s2]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) {
+                if (lm[s2] == -INFINITY) continue;
+                const float wgt = __builtin_amdgcn_exp2f(lm[s2] - M);
+                num = __builtin_fmaf(wgt, lo[s2][d], num);
+                den = __builtin_fmaf(wgt, ll[s2], den);
+            }
+            const int k = head * a.hd + d;
+            a.out_f[xfrag_piece(b, k & ~7, a.out_k32) + (k & 7)] = (half_t)(num / den);
+        }
+        return;
+    }
     if (a.nsplit == 1) {
 #pragma unroll
         for (int d = 0; d < VD16; ++d) {
@@ -1140,13 +1173,21 @@ __global__ void decode_attn_combine_kernel(DecAttnArgs a) {
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s) {
     if (a.kv.page_tokens != 64) return hipErrorInvalidValue;        // the page pipeline is written for 64-token pages (aur_create enforces it)
     dim3 grid(a.nsplit, a.heads, a.B);
+    if (a.local_splits > 1) {                           // all splits of a (sequence, head) in one workgroup: no combine launch
+        if (a.local_splits != a.nsplit || a.kv.kblk != 4 || a.kv.vd16 != 8) return hipErrorInvalidValue;
+        grid.x = 1;
+        if (a.nsplit == 2) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8, 2>), grid, dim3(128), 0, s, a);
+        else if (a.nsplit == 4) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8, 4>), grid, dim3(256), 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (a.kv.kblk == 4 && a.kv.vd16 == 8) hipLaunchKernelGGL((decode_attn_dot_kernel<4, 8>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 2 && a.kv.vd16 == 4) hipLaunchKernelGGL((decode_attn_dot_kernel<2, 4>), grid, dim3(64), 0, s, a);
     else if (a.kv.kblk == 1 && a.kv.vd16 == 2) hipLaunchKernelGGL((decode_attn_dot_kernel<1, 2>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-bool decode_attention_needs_combine(const DecAttnArgs& a) { return a.nsplit > 1; }     // a single split normalises and stores its output itself
+bool decode_attention_needs_combine(const DecAttnArgs& a) { return a.nsplit > 1 && a.local_splits <= 1; }     // a single split normalises and stores its output itself
 hipError_t launch_decode_attention_combine(const DecAttnArgs& a, hipStream_t s) {
     if (!decode_attention_needs_combine(a)) return hipSuccess;
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.heads, a.B), dim3(a.hd <= 64 ? 64 : 128), 0, s, a);

@@ -84,6 +84,7 @@ struct aur_ctx {
     int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
+    int attn_local = 1;                                                         // 1: workgroup-local join of the decode attention's splits where it applies (mk_dec_attn); 0 = always decode_attn_combine_kernel (A/B and test)
     int tome_fused_ln = 1;                                                      // 1: LayerNorm 2 of a merging ViT layer comes out of the ToMe merge launch (bitwise norm_kernel's result; 0 = its own launch, A/B and test only)
     int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
@@ -1137,6 +1138,9 @@ static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
     at.qbuf = ctx->d_q; at.kv = llm_kv(ctx, l); at.pos = ctx->s_pos; at.seq_ids = nullptr; at.B = ctx->batch; at.heads = g.llm_heads;
     at.hd = ctx->l_hd; at.nsplit = ctx->nsplit; at.pages_per_split = ctx->pps; at.scale = 1.0f / sqrtf((float)ctx->l_hd);
     at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32;
+    // engines whose capacity alone gives one attention workgroup per CU and still split the context (8-15 slots of 32 heads): the splits of a
+    // (sequence, head) are the waves of one workgroup and meet in LDS - bitwise the two-launch result, one launch per layer less
+    at.local_splits = (g.max_batch * g.llm_heads >= 256 && (ctx->nsplit == 2 || ctx->nsplit == 4) && ctx->l_hd == 128 && ctx->attn_local) ? ctx->nsplit : 0;
     return at;
 }
 static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
@@ -1293,6 +1297,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         return AUR_OK;
     }
     if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
+    else if (!strcmp(name, "dec_attn_local")) ctx->attn_local = value ? 1 : 0;
     else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = ctx->skinny_variant_wide = value ? 1 : 0;
     else if (!strcmp(name, "skinny_variant_wide")) ctx->skinny_variant_wide = value ? 1 : 0;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;

@@ -184,6 +184,7 @@ struct DecAttnArgs {
     float* part_ml;         // [B][heads][nsplit][2]
     half_t* out_f;          // [B, heads*hd] in x-fragment form (K32 = out_k32 = heads*hd/32)
     int out_k32;
+    int local_splits;       // > 1 (== nsplit, 2 or 4): the splits of a (sequence, head) are the waves of ONE workgroup, joined through LDS (no combine launch)
 };
 hipError_t launch_decode_attention(const DecAttnArgs& a, hipStream_t s);            // main + combine
 hipError_t launch_decode_attention_main(const DecAttnArgs& a, hipStream_t s);

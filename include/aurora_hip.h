@@ -213,6 +213,8 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 /* Tuning knobs (invalidate the captured decode graph): "decode_fused_reduce" 0 (default: the split-K residual projections are followed by
  * a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same), "tome_fused_ln" 1 (default: LayerNorm 2 of a
  * merging ViT layer comes out of the ToMe merge launch) / 0 (its own launch; bitwise the same),
+ * "dec_attn_local" 1 (default: on engines of 8-15 slots x 32 heads the splits of a (sequence, head) are the waves of one attention workgroup,
+ * joined through LDS) / 0 (decode_attn_combine_kernel joins them; bitwise the same),
  * "dec_attn_pps" pages per
  * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_nt_out" -1 (default: GEMM outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always),

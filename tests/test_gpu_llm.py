@@ -366,3 +366,40 @@ def test_pruned_last_prefill_layer_is_bitwise_the_full_one(name, L, nseq):
         eng.close()
 
 
+
+
+@pytest.mark.parametrize("batch,pps", [(8, 0), (8, 4), (12, 0)])
+def test_workgroup_local_attention_splits_are_bitwise_the_combine_kernel(batch, pps):
+    """Round 5: engines of 8-15 slots x 32 heads give the decode attention one workgroup per CU and still split every context in 2 (or 4);
+    the splits of a (sequence, head) are then the WAVES of one workgroup, joined through LDS behind a barrier instead of through global
+    partials and decode_attn_combine_kernel.  Same operations in the same order: ids and logits bit for bit against `dec_attn_local` 0,
+    ragged contexts (a split with no page of its own included), eager and as a hipGraph."""
+    cfg = dict(LLM_CFGS["hd128"], num_attention_heads=32, hidden_size=4096, intermediate_size=512, num_hidden_layers=1)
+    gen = torch.Generator().manual_seed(700 + batch)
+    lens = [700 - 41 * b for b in range(batch)]
+    embs = [(torch.randn(L, cfg["hidden_size"], generator=gen) * 0.5).half().float() for L in lens]
+    res = {}
+    for use_graph in (False, True):
+        eng, w = make_engine(cfg, 29, max_batch=batch, use_graph=use_graph, max_ctx=1024, max_new=12)
+        try:
+            for local in (1, 0, 1):
+                eng.set_option("dec_attn_local", local)
+                if pps:
+                    eng.set_option("dec_attn_pps", pps)
+                eng.begin_batch(batch, 12, None)
+                for b in range(batch):
+                    eng.prefill(b, padded(embs[b]), lens[b])
+                logits = []
+                for _ in range(6):
+                    eng.decode(1)
+                    logits.append(eng.logits().clone())
+                cur = (eng.outputs(), torch.stack(logits))
+                if (use_graph, local) in res:
+                    assert cur[0] == res[(use_graph, local)][0] and torch.equal(cur[1], res[(use_graph, local)][1])
+                res[(use_graph, local)] = cur
+        finally:
+            eng.close()
+    base = res[(False, 0)]
+    for key, cur in res.items():
+        assert cur[0] == base[0], key
+        assert torch.equal(cur[1], base[1]), key
