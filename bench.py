@@ -120,6 +120,8 @@ def parse():
     p.add_argument("--tiny", action="store_true", help="tiny model dims (plumbing check only; result is not the metric)")
     p.add_argument("--tiny-deep", action="store_true", help="host-side rehearsal: tiny widths but the REAL layer counts (31 ViT + 32 Llama layers), so that a cycle "
                    "enqueues the real number of launches with kernels of a few microseconds - what the host of an 8-rank node has to sustain (`host` in the line)")
+    p.add_argument("--no-sequential-point", action="store_true", help="skip the one cycle of the sequential schedule that a default run times beside the line "
+                   "(the child processes of the frontier points pass it)")
     p.add_argument("--no-single-stream", action="store_true", help="skip the one-slot operating point (`single_stream`: the reference's own use, inference.py:89-96 / "
                    "EVAL.md 'batch size 1 only'), which the default cfg2 run measures in a child process after the timed steps")
     p.add_argument("--frontier", action="store_true", help="also measure the (captions/s, p50 TTFT) points of prefill groups 1 / 2 / 8 in child processes (minutes); "
@@ -322,7 +324,7 @@ def self_launch(n: int) -> int:
 def child_point(flags, timeout=1200):
     """One more operating point of this benchmark in a child process (its own engine); -> the child's JSON line, or None."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--no-cpu-baseline", "--no-power", "--no-single-stream", "--no-latency-point"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--no-cpu-baseline", "--no-power", "--no-single-stream", "--no-latency-point", "--no-sequential-point"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
         lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -583,7 +585,7 @@ def main():
             except (RuntimeError, OSError, AttributeError) as e:      # no CU-mask support here: keep the sequential schedule
                 print(f"bench.py: CU-masked streams unavailable ({e}); front ends run between decode chunks", file=sys.stderr)
                 overlap = False
-        if overlap:
+        if overlap and not args.no_sequential_point:
             # one cycle of the sequential schedule first (front ends BETWEEN decode chunks on one stream): the latency-oriented
             # operating point, reported beside the line
             torch.cuda.synchronize()
@@ -596,6 +598,7 @@ def main():
                          "p50_ttft_ms": float(np.median([a.elapsed_time(b) for a, b in lat_ev])),
                          "note": "one cycle with each group's front end run between two decode chunks on the decode stream (--overlap 0)"}
             lat_ev.clear()
+        if overlap:
             # ---- the front end of a group's NEXT clips runs on its own stream, restricted to `fc` CUs of every XCD, while all B
             #      slots keep decoding (HBM-bound decode next to MFMA-bound ViT / prefill): aur_llm_prefill_stage writes spare KV
             #      sequences B .. B + G - 1, and at the group's boundary aur_llm_prefill_commit (decode stream) exchanges page-table
