@@ -253,3 +253,61 @@ def test_rank_cpu_slices_are_disjoint_and_cover_the_numa_node():
     assert rank_cpu_slice(node, [5], 5) == node                # alone on its node: all of it
     assert rank_cpu_slice([7], [0, 1], 1) == [7]               # fewer cores than ranks: never empty
     assert rank_cpu_slice(node, [0, 1], 3) == node             # not among the sharers: untouched
+
+
+def test_observe_records_the_worst_value_and_asserts_the_bound(tmp_path, monkeypatch):
+    """tests.util.observe: the recorder behind profiles/r05_parity_observed.json (asserts the frozen bound, keeps the worst value per key,
+    merges with the record of earlier test processes of the same run)."""
+    import json
+    import pytest
+    from tests import util
+    monkeypatch.setattr(util, "_OBSERVED", {})
+    util.observe("k/le", 0.2, 1.0)
+    util.observe("k/le", 0.7, 1.0)
+    util.observe("k/le", 0.4, 1.0)
+    util.observe("k/ge", 9, 5, at_least=True)
+    util.observe("k/ge", 6, 5, at_least=True)
+    assert util._OBSERVED["k/le"] == {"worst": 0.7, "n": 3, "bound": 1.0, "kind": "<="}
+    assert util._OBSERVED["k/ge"] == {"worst": 6.0, "n": 2, "bound": 5.0, "kind": ">="}
+    with pytest.raises(AssertionError):
+        util.observe("k/le", 1.5, 1.0)
+    with pytest.raises(AssertionError):
+        util.observe("k/ge", 4, 5, at_least=True)
+    # flush merges into an existing file of the same run
+    root = tmp_path / "repo"
+    (root / "tests").mkdir(parents=True)
+    (root / "gpurun_out").mkdir()
+    (root / "gpurun_out" / "parity_observed.json").write_text(json.dumps({"k/le": {"worst": 0.9, "n": 2, "bound": 1.0, "kind": "<="}}))
+    monkeypatch.setattr(util.os.path, "abspath", lambda p: str(root / "tests" / "util.py"))
+    monkeypatch.setattr(util, "_OBSERVED", {"k/le": {"worst": 0.7, "n": 3, "bound": 1.0, "kind": "<="}, "k/new": {"worst": 1.0, "n": 1, "bound": 2.0, "kind": "<="}})
+    util._flush_observed()
+    got = json.loads((root / "gpurun_out" / "parity_observed.json").read_text())
+    assert got["k/le"]["worst"] == 0.9 and got["k/le"]["n"] == 5 and got["k/new"]["n"] == 1
+
+
+def test_bench_child_point_reads_the_last_json_line_and_survives_failures(tmp_path, monkeypatch):
+    """bench.child_point: the operating points a default run measures in child processes (`single_stream`, the latency-first frontier
+    point) - the child's LAST JSON line is the result; a child that crashes or prints nothing yields None and the parent's line still prints."""
+    import subprocess
+    import bench
+    calls = []
+
+    class R:
+        def __init__(self, out):
+            self.stdout, self.stderr, self.returncode = out, "", 0
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        return R('warming up\n{"value": 1.0}\nnoise\n{"value": 2.5, "p50_ttft_ms": 40.0}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    got = bench.child_point(["--batch", "1"])
+    assert got == {"value": 2.5, "p50_ttft_ms": 40.0}
+    assert calls[0][2:4] == ["--batch", "1"] and {"--no-cpu-baseline", "--no-single-stream", "--no-latency-point", "--no-sequential-point"} <= set(calls[0])
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: R("no json here\n"))
+    assert bench.child_point(["--batch", "1"]) is None
+
+    def boom(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, 1)
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert bench.child_point(["--batch", "1"]) is None
+    assert bench.masked_steps_per_chunk(240.0, 36.7, 8) == 7 and bench.masked_steps_per_chunk(10.0, 36.7, 8) == 1 and bench.masked_steps_per_chunk(900.0, 36.7, 8) == 8
