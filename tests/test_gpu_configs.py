@@ -99,6 +99,33 @@ def test_llama_7b_width_prefill_and_decode_logits():
         eng.close()
 
 
+@pytest.mark.parametrize("name,L", [("cfg3", 2766), ("cfg5", 4870)])
+def test_llama_7b_width_prefill_at_the_other_configs_prefix_lengths_vs_fp32(name, L):
+    """cfg3 / cfg5 at full size had met property checks only.  Their prefix lengths (16 x 171 + 30 = 2766 and
+    8 x 605 + 30 = 4870 rows: 44 / 77 pages, 22 / 39 causal query blocks) through 2 layers at Llama-7B width: the first token's logits
+    (last prompt position) and the five decode steps after it against one teacher-forced fp32 pass of the oracle."""
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.test_gpu_llm import padded, teacher_forced_logits
+    cfg = LLAMA_7B_WIDTH
+    w = rand_llm_weights(cfg, 3, wstd=0.02)
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": w}, max_frames=1, max_batch=1, max_ctx=(L + 16 + 63) // 64 * 64, max_new_tokens=8)
+    try:
+        emb = (torch.randn(L, 4096, generator=torch.Generator().manual_seed(len(name) + L)) * 0.5).half().float()
+        eng.begin_batch(1, 6, None)
+        eng.prefill(0, padded(emb), L)
+        logits = [eng.logits()[0].cpu()]
+        for _ in range(5):
+            eng.decode(1)
+            logits.append(eng.logits()[0].cpu())
+        ids = eng.outputs()[0]
+    finally:
+        eng.close()
+    ref = teacher_forced_logits(emb, ids, w, cfg)
+    scale = ref.abs().max().item()
+    for i in range(6):
+        observe(f"configs/llama7b_width_{name}_prefix_logits_over_scale", (logits[i] - ref[i]).abs().max().item() / scale, LOGIT_TOL_WIDE)
+
+
 def test_long_kv_decode_many_pages_cfg5_shape():
     """cfg5 shape: prefix 4870, 2048 new tokens (context grows to 6.9k = 108 pages, 27 attention splits) on a small-width
     model: teacher-forced logits at the start, middle and end of the generation, graph == eager."""
