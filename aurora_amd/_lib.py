@@ -77,6 +77,11 @@ SIGNATURES = {
     "aur_slot_retire": (C.c_int, [_P, _I, _P]),
     "aur_slot_state": (C.c_int, [_P, _IP, _IP, _P]),
     "aur_slot_collect": (C.c_int, [_P, _I, _I, _P, _P, _P]),
+    "aur_graph_begin": (C.c_int, [_P, _P]),
+    "aur_graph_end": (C.c_int, [_P, _P, _IP, C.POINTER(_L)]),
+    "aur_graph_launch": (C.c_int, [_P, _I, _P]),
+    "aur_graph_destroy": (C.c_int, [_P, _I]),
+    "aur_decode_stamps_read": (C.c_int, [_P, C.POINTER(C.c_double), _I, C.POINTER(_L), _IP, _P]),
     "aur_tome_step": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aur_linear": (C.c_int, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "aur_linear_skinny": (C.c_int, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),

@@ -13,6 +13,7 @@
 //  * MFMA 16x16x32 C/D map (guide section 3): lane holds D[row = 4*(lane>>4) + i][col = lane & 15], i = 0..3.
 #pragma once
 #define AUR_MAX_BATCH 128    /* decode slots per bank: up to 8 MFMA column groups of 16 batch rows (KV at 128 x 2.4k tokens: 156 of 288 GB) */
+#define AUR_STAMP_RING 4096 /* decode steps whose in-loop attention interval is kept (option "decode_stamp_layer") */
 #define AUR_SSQ_SLOTS 16     /* stripes of the sum(x^2) accumulators (power of two): decode.hip ssq_to_rstd */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -117,7 +118,7 @@ struct KvLayout {
     half_t* base;            // layer base
     const int32_t* page_table;   // [seq][max_pages] or nullptr (page id = seq)
     int max_pages;           // row length of page_table
-    int page_tokens;         // multiple of 32
+    int page_tokens;         // LLM cache: 64 (aur_create); ViT scratch: the padded token count, a multiple of 32
     int heads;
     int kblk;                // d-blocks of 32 per head in K fragments (hd_pad / 32)
     int vd16;                // d16 tiles per head in V fragments (hd / 16)

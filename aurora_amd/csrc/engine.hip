@@ -104,6 +104,18 @@ struct aur_ctx {
     } banks[2];
     int nbanks = 1, cur_bank = 0;
     const int32_t* ptab_cur = nullptr;
+    // caller-captured hipGraphs (aur_graph_begin / aur_graph_end / aur_graph_launch): a front end per shape bucket
+    struct UserGraph {
+        hipGraphExec_t exec = nullptr;
+        int64_t nodes = 0;
+    };
+    std::vector<UserGraph> ugraphs;                      // handle = index + 1; destroyed slots keep exec == nullptr
+    bool capturing = false;
+    hipStream_t cap_stream = nullptr;
+    // in-loop timing of the dominant decode kernel: option "decode_stamp_layer" brackets that layer's attention launch with two
+    // one-thread launches that store the device's constant-rate clock (part of the captured step, so the timed loop itself is measured)
+    int stamp_layer = -1;
+    unsigned long long* d_stamp = nullptr;               // [0] steps stamped so far, [8 + 2 * (step % AUR_STAMP_RING) + {0, 1}] begin / end
     // profiling
     bool prof = false;
     std::unordered_map<std::string, StageTimer> timers;
@@ -131,6 +143,13 @@ static int aur_fail(aur_ctx* ctx, int code, const char* fmt, ...) {
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// Entry points that synchronise (or destroy graphs) refuse to run inside aur_graph_begin / aur_graph_end BEFORE touching the runtime:
+// a synchronising HIP call on a capturing stream invalidates the capture and (ROCm 7.2) leaves the stream refusing later launches
+#define NO_CAPTURE(who)                                                                                                     \
+    do {                                                                                                                    \
+        if (ctx->capturing) return aur_fail(ctx, AUR_ERR_STATE, "%s inside aur_graph_begin / aur_graph_end: it synchronises", who); \
     } while (0)
 
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
@@ -282,6 +301,7 @@ static int64_t carve(aur_ctx* c, char* base) {
     c->d_scr = k.take<half_t>(AUR_MAX_BATCH * 16384);                 // scratch x-fragments for aur_linear_skinny
     c->d_part_row = k.take<float>((int64_t)4 * (c->l_dpad / 16) * (Bp / 16) * 256);          // [4 k splits][tiles][column groups][64 lanes][4]
     c->d_row_cnt = k.take<int>(c->l_dpad / 16);
+    c->d_stamp = k.take<unsigned long long>(8 + 2 * AUR_STAMP_RING);
     c->d_part_o = k.take<float>(B * g.llm_heads * c->l_max_pages * c->l_hd);     // room for pages_per_split = 1
     c->d_part_ml = k.take<float>(B * g.llm_heads * c->l_max_pages * 2);
     c->s_ptab = k.take<int32_t>(2 * (int64_t)c->kv_seqs * c->l_max_pages);
@@ -334,6 +354,8 @@ extern "C" void aur_destroy(aur_ctx* ctx) {
         if (K.graph) (void)hipGraphExecDestroy(K.graph);
         if (K.graph_h) (void)hipGraphExecDestroy(K.graph_h);
     }
+    for (auto& ug : ctx->ugraphs)
+        if (ug.exec) (void)hipGraphExecDestroy(ug.exec);
     for (auto& kv : ctx->timers) {
         if (kv.second.e0) (void)hipEventDestroy(kv.second.e0);
         if (kv.second.e1) (void)hipEventDestroy(kv.second.e1);
@@ -364,6 +386,7 @@ extern "C" int aur_set_workspace(aur_ctx* ctx, void* p, int64_t n) {
     carve(ctx, ctx->ws);
     ctx->finalized = false;
     if (ctx->d_row_cnt) CK(hipMemset(ctx->d_row_cnt, 0, (size_t)(ctx->l_dpad / 16) * 4));     // split-K arrival counters, likewise
+    if (ctx->d_stamp) CK(hipMemset(ctx->d_stamp, 0, (size_t)(8 + 2 * AUR_STAMP_RING) * 8));
     return AUR_OK;
 }
 extern "C" int aur_set_kv_pool(aur_ctx* ctx, void* p, int64_t n) {
@@ -390,6 +413,7 @@ static bool get(aur_ctx* c, const std::string& name, const T** out, int64_t min_
 }
 
 extern "C" int aur_finalize(aur_ctx* ctx, void* stream) {
+    NO_CAPTURE("aur_finalize");
     if (!ctx->ws) return aur_fail(ctx, AUR_ERR_STATE, "aur_finalize: workspace not set");
     const aur_config& g = ctx->cfg;
     hipStream_t s = (hipStream_t)stream;
@@ -512,7 +536,7 @@ static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
         tr.range_id = roctx().start(name);
         tr.range_open = true;
     }
-    if (!c->prof) return;
+    if (!c->prof || c->capturing) return;
     StageTimer& t = c->timers[name];
     if (!t.e0) {
         (void)hipEventCreate(&t.e0);
@@ -533,13 +557,14 @@ static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
         if (tr.range_open) roctx().stop(tr.range_id);
         tr.range_open = false;
     }
-    if (!c->prof) return;
+    if (!c->prof || c->capturing) return;
     StageTimer& t = c->timers[name];
     (void)hipEventRecord(t.e1, s);
     t.open = true;
     t.launches++;
 }
 extern "C" int aur_profile_enable(aur_ctx* ctx, int32_t on) {
+    NO_CAPTURE("aur_profile_enable");
     ctx->prof = on != 0;
     for (auto& kv : ctx->timers) {
         kv.second.ms = 0;
@@ -895,6 +920,7 @@ static void drop_graphs(aur_ctx* ctx) {
 }
 
 extern "C" int aur_begin_batch(aur_ctx* ctx, int32_t batch, int32_t max_new_tokens, int32_t eos_id, void* stream) {
+    NO_CAPTURE("aur_begin_batch");
     if (!ctx->finalized || ctx->ll.empty()) return aur_fail(ctx, AUR_ERR_STATE, "aur_begin_batch: language weights not finalized");
     const aur_config& g = ctx->cfg;
     if (batch < 1 || batch > g.max_batch) return aur_fail(ctx, AUR_ERR_ARG, "batch %d outside [1, %d]", batch, g.max_batch);
@@ -1173,6 +1199,16 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     return dn;
 }
 
+// One thread stores the device's constant-rate clock (wall_clock64: hipDeviceAttributeWallClockRate kHz) for step `n` = ring[0];
+// the closing stamp advances the step count.  Two of these bracket ONE layer's attention launch inside the captured decode step when
+// option "decode_stamp_layer" is set: the interval they give is that kernel's duration in the loop the caller actually runs (beside a
+// front end, on a CU-masked stream, replayed from the graph) plus two kernel boundaries (~3 us).
+__global__ void stamp_kernel(unsigned long long* __restrict__ ring, int which) {
+    const unsigned long long n = ring[0];
+    ring[8 + 2 * (n % AUR_STAMP_RING) + which] = (unsigned long long)wall_clock64();
+    if (which) ring[0] = n + 1;
+}
+
 static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
     const aur_config& g = ctx->cfg;
     const int B = ctx->batch;
@@ -1180,8 +1216,11 @@ static int enqueue_decode_step(aur_ctx* ctx, hipStream_t s, bool instrument) {
         CK(launch_skinny(mk_dec_qkv(ctx, l), s));
         {
             const DecAttnArgs at = mk_dec_attn(ctx, l);
+            const bool stamp = l == ctx->stamp_layer && ctx->d_stamp && !instrument;
             if (instrument) kev_begin(ctx->kev[0], s);
+            if (stamp) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, ctx->d_stamp, 0);
             CK(launch_decode_attention_main(at, s));
+            if (stamp) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, ctx->d_stamp, 1);
             if (instrument) kev_end(ctx->kev[0], s);
             CK(launch_decode_attention_combine(at, s));
         }
@@ -1199,6 +1238,7 @@ extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
     if (!ctx->finalized || ctx->ll.empty() || ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_decode: call aur_begin_batch / aur_llm_prefill first");
     hipStream_t s = (hipStream_t)stream;
     if (steps <= 0) return AUR_OK;
+    if (ctx->capturing) return aur_fail(ctx, AUR_ERR_STATE, "aur_llm_decode inside aur_graph_begin / aur_graph_end: the decode step replays its own graph");
     stage_begin(ctx, "decode", s);
     const bool use_graph = ctx->cfg.use_graph && !ctx->prof;
     if (use_graph) {
@@ -1226,7 +1266,105 @@ extern "C" int aur_llm_decode(aur_ctx* ctx, int32_t steps, void* stream) {
     return AUR_OK;
 }
 
+// In-loop intervals of the stamped attention launch (option "decode_stamp_layer"): the last min(cap, steps stamped, AUR_STAMP_RING)
+// steps, oldest first, in microseconds.  Synchronises the stream.
+extern "C" int aur_decode_stamps_read(aur_ctx* ctx, double* us_out, int32_t cap, int64_t* steps_total_out, int32_t* n_out, void* stream) {
+    NO_CAPTURE("aur_decode_stamps_read");
+    if (!ctx->d_stamp || !us_out || cap < 1 || !n_out) return aur_fail(ctx, AUR_ERR_ARG, "aur_decode_stamps_read: workspace not set or null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<unsigned long long> h(8 + 2 * AUR_STAMP_RING);
+    CK(hipMemcpyAsync(h.data(), ctx->d_stamp, h.size() * 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    int dev = 0, khz = 0;
+    CK(hipGetDevice(&dev));
+    CK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    if (khz <= 0) return aur_fail(ctx, AUR_ERR_HIP, "hipDeviceAttributeWallClockRate = %d", khz);
+    const unsigned long long total = h[0];
+    int64_t n = (int64_t)(total < (unsigned long long)AUR_STAMP_RING ? total : AUR_STAMP_RING);
+    if (n > cap) n = cap;
+    for (int64_t i = 0; i < n; ++i) {
+        const unsigned long long step = total - (unsigned long long)n + (unsigned long long)i;
+        const unsigned long long t0 = h[8 + 2 * (step % AUR_STAMP_RING)], t1 = h[8 + 2 * (step % AUR_STAMP_RING) + 1];
+        us_out[i] = (double)(t1 - t0) * 1e3 / (double)khz;
+    }
+    if (steps_total_out) *steps_total_out = (int64_t)total;
+    *n_out = (int32_t)n;
+    return AUR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ caller-captured graphs
+// The front end of a clip (or of a group of equal-shape clips) is ~600 launches whose arguments depend only on the shape bucket
+// (frames, input size, r, prompt structure, target KV sequences) once the inputs sit in fixed staging buffers.  A serving loop captures
+// that call sequence once per bucket and replays it with one call - the design the reference tree's serving engine uses for its decode
+// step (src/sglang/python/sglang/srt/model_executor/cuda_graph_runner.py:163-279: one captured graph per shape bucket, inputs copied
+// into the graph's static buffers before each replay).  Everything between begin and end must be enqueue-only calls of THIS ctx on
+// THIS stream from THIS thread (aur_vit_encode*, aur_project_splice, aur_llm_prefill_batch / _stage / _commit, aur_slot_reset /
+// _retire / _collect, the kernel-level entry points); calls that synchronise (aur_get_outputs, aur_unfinished, aur_slot_state,
+// aur_microbench, aur_decode_stamps_read, aur_set_option on a dec_* knob) and aur_llm_decode (it replays its own graph) are rejected by
+// the runtime and fail the capture.  Kernel arguments, including the ctx's gemm_* knobs, are frozen at capture time.
+extern "C" int aur_graph_begin(aur_ctx* ctx, void* stream) {
+    if (!ctx->finalized) return aur_fail(ctx, AUR_ERR_STATE, "aur_graph_begin: weights not finalized");
+    if (ctx->capturing) return aur_fail(ctx, AUR_ERR_STATE, "aur_graph_begin: a capture is already open on this ctx");
+    if (ctx->prof) return aur_fail(ctx, AUR_ERR_STATE, "aur_graph_begin: per-stage profiling is on (aur_profile_enable): its events cannot be captured");
+    CK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    ctx->cap_stream = (hipStream_t)stream;
+    return AUR_OK;
+}
+// Ends the capture opened by aur_graph_begin (always - also after a failed call in between) and instantiates the graph.
+// *graph_out: handle >= 1 for aur_graph_launch; *nodes_out (may be NULL): number of graph nodes.
+extern "C" int aur_graph_end(aur_ctx* ctx, void* stream, int32_t* graph_out, int64_t* nodes_out) {
+    if (!ctx->capturing) return aur_fail(ctx, AUR_ERR_STATE, "aur_graph_end: no capture is open");
+    if ((hipStream_t)stream != ctx->cap_stream) return aur_fail(ctx, AUR_ERR_ARG, "aur_graph_end: not the stream aur_graph_begin was given");
+    ctx->capturing = false;
+    hipGraph_t gr = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &gr);
+    if (e != hipSuccess || !gr) {
+        // a call of the CALLER's inside the capture synchronised: make sure the stream has really left capture mode and drop the sticky error
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            hipGraph_t g2 = nullptr;
+            (void)hipStreamEndCapture((hipStream_t)stream, &g2);
+            if (g2) (void)hipGraphDestroy(g2);
+        }
+        (void)hipGetLastError();
+        return aur_fail(ctx, AUR_ERR_HIP, "hipStreamEndCapture: %s (a call inside the capture synchronised or failed)", hipGetErrorString(e));
+    }
+    if (!graph_out) {
+        (void)hipGraphDestroy(gr);
+        return aur_fail(ctx, AUR_ERR_ARG, "aur_graph_end: graph_out is NULL");
+    }
+    size_t n = 0;
+    (void)hipGraphGetNodes(gr, nullptr, &n);
+    aur_ctx::UserGraph ug;
+    e = hipGraphInstantiate(&ug.exec, gr, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) return aur_fail(ctx, AUR_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    ug.nodes = (int64_t)n;
+    size_t slot = 0;
+    while (slot < ctx->ugraphs.size() && ctx->ugraphs[slot].exec) ++slot;
+    if (slot == ctx->ugraphs.size()) ctx->ugraphs.push_back(ug);
+    else ctx->ugraphs[slot] = ug;
+    *graph_out = (int32_t)slot + 1;
+    if (nodes_out) *nodes_out = ug.nodes;
+    return AUR_OK;
+}
+extern "C" int aur_graph_launch(aur_ctx* ctx, int32_t graph, void* stream) {
+    if (graph < 1 || graph > (int32_t)ctx->ugraphs.size() || !ctx->ugraphs[graph - 1].exec) return aur_fail(ctx, AUR_ERR_ARG, "aur_graph_launch: unknown graph %d", graph);
+    if (ctx->capturing) return aur_fail(ctx, AUR_ERR_STATE, "aur_graph_launch: a capture is open on this ctx");
+    CK(hipGraphLaunch(ctx->ugraphs[graph - 1].exec, (hipStream_t)stream));
+    return AUR_OK;
+}
+// The caller guarantees that no launch of the graph is still queued or running (its own event / stream synchronisation).
+extern "C" int aur_graph_destroy(aur_ctx* ctx, int32_t graph) {
+    if (graph < 1 || graph > (int32_t)ctx->ugraphs.size() || !ctx->ugraphs[graph - 1].exec) return aur_fail(ctx, AUR_ERR_ARG, "aur_graph_destroy: unknown graph %d", graph);
+    (void)hipGraphExecDestroy(ctx->ugraphs[graph - 1].exec);
+    ctx->ugraphs[graph - 1] = aur_ctx::UserGraph{};
+    return AUR_OK;
+}
+
 extern "C" int aur_get_outputs(aur_ctx* ctx, int32_t* ids_host, int32_t* lens_host, void* stream) {
+    NO_CAPTURE("aur_get_outputs");
     hipStream_t s = (hipStream_t)stream;
     if (ids_host) CK(hipMemcpyAsync(ids_host, ctx->s_ids, (size_t)ctx->batch * ctx->max_new * 4, hipMemcpyDeviceToHost, s));
     if (lens_host) CK(hipMemcpyAsync(lens_host, ctx->s_len, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
@@ -1234,6 +1372,7 @@ extern "C" int aur_get_outputs(aur_ctx* ctx, int32_t* ids_host, int32_t* lens_ho
     return AUR_OK;
 }
 extern "C" int aur_unfinished(aur_ctx* ctx, int32_t* count_host, void* stream) {
+    NO_CAPTURE("aur_unfinished");
     hipStream_t s = (hipStream_t)stream;
     std::vector<int32_t> fin(ctx->batch), len(ctx->batch);
     CK(hipMemcpyAsync(fin.data(), ctx->s_fin, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
@@ -1265,6 +1404,7 @@ extern "C" int aur_slot_retire(aur_ctx* ctx, int32_t slot, void* stream) {
     return AUR_OK;
 }
 extern "C" int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, void* stream) {
+    NO_CAPTURE("aur_slot_state");
     if (ctx->batch < 1) return aur_fail(ctx, AUR_ERR_STATE, "aur_slot_state: no active batch");
     hipStream_t s = (hipStream_t)stream;
     if (lens_host) CK(hipMemcpyAsync(lens_host, ctx->s_len, (size_t)ctx->batch * 4, hipMemcpyDeviceToHost, s));
@@ -1288,6 +1428,7 @@ extern "C" int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream) {
 
 // ------------------------------------------------------------------------------------------ tuning / microbench
 extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
+    NO_CAPTURE("aur_set_option");
     if (!strcmp(name, "prefill_prune_last")) {          // 1 (default): the last prefill layer computes Q / attention / MLP for each sequence's last 128 rows only
         ctx->prune_last = value ? 1 : 0;
         return AUR_OK;
@@ -1335,6 +1476,11 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (value < 0 || value > 1) return aur_fail(ctx, AUR_ERR_ARG, "decode_fused_reduce must be 0 or 1");
 #endif
         ctx->fused_reduce = (int)value;
+    } else if (!strcmp(name, "decode_stamp_layer")) {
+        // value >= 0: two one-thread stamp launches bracket that layer's attention launch in every decode step (aur_decode_stamps_read);
+        // -1 (default): none.  The step's graphs are re-captured.
+        if (value < -1 || value >= ctx->cfg.llm_layers) return aur_fail(ctx, AUR_ERR_ARG, "decode_stamp_layer must be -1 or a layer index");
+        ctx->stamp_layer = (int)value;
     } else if (!strcmp(name, "decode_half_grid")) {
         // the following aur_llm_decode calls go to a stream that owns half of the CUs: QKV / gate-up launch half as many workgroups
         // with twice the tiles (decode.hip launch_skx_nb); bitwise the same tokens.  Keeps both captured graphs.
@@ -1352,6 +1498,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
 // back-to-back launches cycling through the layers (so weights stream from HBM, not from the 256 MiB MALL),
 // bracketed by HIP events on `stream`.  Synchronises.  us_out = mean microseconds per launch.
 extern "C" int aur_microbench(aur_ctx* ctx, const char* kernel, int32_t iters, double* us_out, void* stream) {
+    NO_CAPTURE("aur_microbench");
     if (!ctx->finalized || ctx->ll.empty() || ctx->batch < 1 || ctx->last_prefill_len < 1)
         return aur_fail(ctx, AUR_ERR_STATE, "aur_microbench: prefill a batch first");
     hipStream_t s = (hipStream_t)stream;

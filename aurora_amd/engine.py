@@ -306,8 +306,9 @@ class AuroraCapEngine:
         return tome_r(height or v["image_size"], width or v["image_size"], v["patch_size"], token_kept_ratio,
                       v["num_hidden_layers"])
 
-    def vit_encode(self, pixels: torch.Tensor, r: int) -> torch.Tensor:
-        """pixels [F, C, H, W] -> hidden_states[-2][:, 1:]  as fp16 [F, n_kept, D]."""
+    def vit_encode(self, pixels: torch.Tensor, r: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """pixels [F, C, H, W] -> hidden_states[-2][:, 1:]  as fp16 [F, n_kept, D] (into `out` when given: a captured front
+        end must not allocate)."""
         v = self.v
         if pixels.dim() != 4 or pixels.shape[1] != v.get("num_channels", 3):
             raise ValueError(f"pixel_values must be [frames, {v.get('num_channels', 3)}, H, W], got {tuple(pixels.shape)}")
@@ -318,7 +319,10 @@ class AuroraCapEngine:
             raise ValueError(f"a {H}x{W} input has {t0} tokens per frame; this engine holds up to "
                              f"{(self.max_image // v['patch_size']) ** 2 + 1} (max_image {self.max_image})")
         n_kept = tokens_at_layer(t0, r, v["num_hidden_layers"] - 1) - 1
-        out = torch.empty(F, n_kept, v["hidden_size"], dtype=torch.float16, device=self.dev)
+        if out is None:
+            out = torch.empty(F, n_kept, v["hidden_size"], dtype=torch.float16, device=self.dev)
+        else:
+            assert out.shape == (F, n_kept, v["hidden_size"]) and out.dtype == torch.float16 and out.is_contiguous() and out.is_cuda
         nk = C.c_int32(0)
         pos = self.interpolated_pos(H, W)
         check(self.ctx, self.L.aur_vit_encode_hw(self.ctx, px.data_ptr(), F, H, W, pos.data_ptr() if pos is not None else None, r,
@@ -687,6 +691,38 @@ class AuroraCapEngine:
             sD.wait_stream(sF)
             self.set_option("gemm_max_wgs", 0)
 
+    # ------------------------------------------------------------------ captured call sequences (hipGraph)
+    def graph_capture(self, fn):
+        """Record the engine calls `fn()` enqueues on torch's current stream into a hipGraph (aur_graph_begin / aur_graph_end) and
+        return (handle, number of nodes).  `fn` must only make enqueue-only engine calls on pre-allocated tensors: a torch
+        allocation, a synchronisation or `decode` inside it breaks the capture (raised here)."""
+        st = self._stream()
+        check(self.ctx, self.L.aur_graph_begin(self.ctx, st), "aur_graph_begin")
+        gid, nodes = C.c_int32(0), C.c_int64(0)
+        try:
+            fn()
+        except BaseException:
+            self.L.aur_graph_end(self.ctx, st, C.byref(gid), C.byref(nodes))      # always close the capture; its status is secondary
+            if gid.value:
+                self.L.aur_graph_destroy(self.ctx, gid.value)
+            raise
+        check(self.ctx, self.L.aur_graph_end(self.ctx, st, C.byref(gid), C.byref(nodes)), "aur_graph_end")
+        return gid.value, nodes.value
+
+    def graph_launch(self, gid: int):
+        check(self.ctx, self.L.aur_graph_launch(self.ctx, gid, self._stream()), "aur_graph_launch")
+
+    def graph_destroy(self, gid: int):
+        check(self.ctx, self.L.aur_graph_destroy(self.ctx, gid), "aur_graph_destroy")
+
+    def decode_stamps(self, cap: int = 4096):
+        """(microseconds per step of the stamped attention launch, oldest first; total steps stamped) - option
+        "decode_stamp_layer"; synchronises."""
+        buf = (C.c_double * cap)()
+        n, tot = C.c_int32(0), C.c_int64(0)
+        check(self.ctx, self.L.aur_decode_stamps_read(self.ctx, buf, cap, C.byref(tot), C.byref(n), self._stream()), "aur_decode_stamps_read")
+        return np.asarray(buf[:n.value], dtype=np.float64), tot.value
+
     # ------------------------------------------------------------------ kernel-level entry points (tests)
     def tome_step(self, metric: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], r: int):
         F, t, c = metric.shape
@@ -788,3 +824,87 @@ class AuroraCapEngine:
         ms, n = C.c_double(0), C.c_int64(0)
         check(self.ctx, self.L.aur_profile_read(self.ctx, stage.encode(), C.byref(ms), C.byref(n)), "aur_profile_read")
         return ms.value, n.value
+
+
+class FrontEndGraph:
+    """The front end of a GROUP of `group` equal-shape clips - ViT + per-layer ToMe, projector + splice, and the staged prefill
+    of the group into KV sequences [seq0, seq0 + group) - captured once into a hipGraph and replayed with one call.
+
+    The reference tree's own serving engine captures one graph per shape bucket and copies each request's inputs into the graph's
+    static buffers before the replay (src/sglang/python/sglang/srt/model_executor/cuda_graph_runner.py:163-279); the bucket here is
+    (group, frames, H, W, r, prompt structure, seq0), the static buffers are `pixels`, the three splice-plan arrays and `embeds`.
+    A front end is ~600 launches (31 ViT layers x 10 + 32 prefill layers x 8 + splices): replayed from the graph the host submits it
+    in one call, so a serving loop can submit it just before the device can start it (bounded run-ahead: host-observed TTFT stays
+    close to the device's) without starving the front-end stream.
+
+        fg = FrontEndGraph(eng, group, frames, H, W, r, plan, seq0, embeds=emb)     # on the stream that will replay it
+        fg.load(pixels, plans); fg.launch()                                        # per group; then eng.prefill_commit(.., fg.embeds, ..)
+    """
+
+    def __init__(self, eng: "AuroraCapEngine", group: int, frames: int, height: int, width: int, r: int, plan: dict, seq0: int,
+                 embeds: Optional[torch.Tensor] = None, prefill: str = "stage", slot0: int = 0):
+        v, d = eng.v, eng.l["hidden_size"]
+        self.eng, self.group, self.frames, self.r, self.seq0 = eng, group, frames, r, seq0
+        self.seq_len = plan["seq_len"]
+        self.mseq = _rup(self.seq_len, 32)
+        t0 = (height // v["patch_size"]) * (width // v["patch_size"]) + 1
+        self.n_kept = tokens_at_layer(t0, r, v["num_hidden_layers"] - 1) - 1
+        assert not np.isscalar(plan["n_kept"]) or plan["n_kept"] == self.n_kept
+        dev = eng.dev
+        self.pixels = torch.zeros(group * frames, v.get("num_channels", 3), height, width, dtype=torch.float16, device=dev)
+        self.vis = torch.empty(group * frames, self.n_kept, v["hidden_size"], dtype=torch.float16, device=dev)
+        self.embeds = embeds if embeds is not None else torch.zeros(group * self.mseq, d, dtype=torch.float16, device=dev)
+        assert self.embeds.shape[0] >= group * self.mseq and self.embeds.is_contiguous()
+        # the bucket's splice plans: same structure as `plan` (row maps of one prompt), contents replaced per clip by load()
+        self.used, self.nvis, self.ntext = plan["used"], plan["nvis"], plan["ntext"]
+        self.vis_rows = torch.zeros(group, max(self.nvis, 1), dtype=torch.int32, device=dev)
+        self.text_ids = torch.zeros(group, max(self.ntext, 1), dtype=torch.int32, device=dev)
+        self.text_rows = torch.zeros(group, max(self.ntext, 1), dtype=torch.int32, device=dev)
+        self._plans = [dict(seq_len=self.seq_len, used=self.used, n_kept=plan["n_kept"], nvis=self.nvis, ntext=self.ntext,
+                            vis_rows=self.vis_rows[j], text_ids=self.text_ids[j], text_rows=self.text_rows[j]) for j in range(group)]
+        eng.interpolated_pos(height, width)                       # the position table of this input size exists before the capture
+        for j in range(group):
+            self.vis_rows[j].copy_(plan["vis_rows"])
+            self.text_ids[j].copy_(plan["text_ids"])
+            self.text_rows[j].copy_(plan["text_rows"])
+
+        def run():
+            eng.vit_encode(self.pixels, r, out=self.vis)
+            for j in range(group):
+                eng.project_splice(self.vis[j * frames:(j + 1) * frames], plan=self._plans[j], out=self.embeds[j * self.mseq:(j + 1) * self.mseq])
+            if prefill == "stage":
+                eng.prefill_stage(seq0, group, self.embeds, self.seq_len)
+            elif prefill == "batch":
+                eng.prefill_batch(slot0, group, self.embeds, self.seq_len)
+            else:
+                assert prefill == "none"
+
+        run()                                                      # once eagerly: lazily set kernel attributes must not happen inside a capture
+        self.gid, self.nodes = eng.graph_capture(run)
+
+    def load(self, pixels: torch.Tensor, plans: Optional[Sequence[dict]] = None, *, vis_rows=None, text_ids=None, text_rows=None):
+        """Copy a group's inputs into the graph's static buffers (device-to-device on torch's current stream).  plans: the clips'
+        `splice_plan`s (same structure as the bucket's), or stacked [group, n] int32 arrays through the keyword arguments."""
+        self.pixels.copy_(pixels.reshape(self.pixels.shape), non_blocking=True)
+        if plans is not None:
+            assert len(plans) == self.group
+            for j, pl in enumerate(plans):
+                if (pl["seq_len"], pl["used"], pl["nvis"], pl["ntext"]) != (self.seq_len, self.used, self.nvis, self.ntext):
+                    raise ValueError("splice plan of another shape bucket")
+                self.vis_rows[j, :self.nvis].copy_(pl["vis_rows"], non_blocking=True)
+                self.text_ids[j, :self.ntext].copy_(pl["text_ids"], non_blocking=True)
+                self.text_rows[j, :self.ntext].copy_(pl["text_rows"], non_blocking=True)
+        if vis_rows is not None:
+            self.vis_rows.copy_(vis_rows, non_blocking=True)
+        if text_ids is not None:
+            self.text_ids.copy_(text_ids, non_blocking=True)
+        if text_rows is not None:
+            self.text_rows.copy_(text_rows, non_blocking=True)
+
+    def launch(self):
+        self.eng.graph_launch(self.gid)
+
+    def close(self):
+        if self.gid:
+            self.eng.graph_destroy(self.gid)
+            self.gid = 0

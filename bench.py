@@ -126,6 +126,14 @@ def parse():
                    "EVAL.md 'batch size 1 only'), which the default cfg2 run measures in a child process after the timed steps")
     p.add_argument("--frontier", action="store_true", help="also measure the (captions/s, p50 TTFT) points of prefill groups 1 / 2 / 8 in child processes (minutes); "
                    "without it the line's `frontier` holds the three schedules this run times anyway")
+    p.add_argument("--front-graph", type=int, default=1, choices=[0, 1],
+                   help="overlapped schedule: 1 (default) = a group's front end (ViT + ToMe + projector / splice + staged prefill) is ONE captured hipGraph "
+                        "(engine.FrontEndGraph: inputs copied into static buffers, one replay per group); 0 = ~500 eager launches per group.  Same ids")
+    p.add_argument("--ttft-gate-steps", type=int, default=0,
+                   help="overlapped schedule: bounded run-ahead - the host submits a group's front end only when the device is within this many decode steps of "
+                        "the end of the PREVIOUS chunk (the commit that precedes the front end's start), so that the host-observed submit -> first-token "
+                        "time stays close to the device interval; -1 = unbounded (rounds 2-5: the enqueue thread ran > 1 s ahead)")
+    p.add_argument("--no-stamps", action="store_true", help="do not stamp the decode attention of one layer inside the captured step (roofline.frac_in_timed_loop)")
     p.add_argument("--ttft-delay-steps", type=int, default=-1, help="overlapped schedule: the front end of a group starts this many decode steps after the previous "
                    "boundary instead of at it (-1 = calibrated in the warm-up cycle so that it finishes just before its own boundary: no commit wait)")
     p.add_argument("--config", choices=sorted(CONFIGS), default=None,
@@ -436,6 +444,10 @@ def main():
         eng.set_option("gemm_nt_out", args.gemm_nt_out)
     if args.dec_attn_pps > 0:
         eng.set_option("dec_attn_pps", args.dec_attn_pps)
+    stamp_layer = -1 if args.no_stamps else l["num_hidden_layers"] // 2
+    if stamp_layer >= 0:
+        eng.set_option("decode_stamp_layer", stamp_layer)         # two one-thread launches around that layer's attention, part of the captured step
+    stamps_timed = None
 
     # synthetic inputs, resident in HBM before the timed region.  Clip i of the job's world * B clips belongs to rank i % world - the
     # reference harness's round-robin `islice(docs, rank, None, world_size)` (lmms_eval/utils.py:675-681, aurora_amd.parallel.shard_clips).
@@ -620,6 +632,7 @@ def main():
                 eng.set_option("gemm_max_wgs", 8 * fc)
             pending = [None]
             stage_ev = []
+            stage_ev_eager = []
 
             # host-observed TTFT ("submit -> first generated token id on host"): the host clock from the moment a group's
             # front end is submitted to the moment its first token ids have landed in pinned host memory.  A side stream waits for the
@@ -641,6 +654,7 @@ def main():
                     key, ev = item
                     ev.synchronize()
                     start_stamp[key] = time.perf_counter()
+                    start_q.task_done()
 
             def poller():
                 while True:
@@ -657,6 +671,7 @@ def main():
                         time.sleep(0.001)
                     if key in start_stamp:
                         host_ttft.append(1e3 * (now - start_stamp[key]))
+                    host_q.task_done()
 
             poll_thread = threading.Thread(target=poller, daemon=True)
             start_thread = threading.Thread(target=start_poller, daemon=True)
@@ -664,19 +679,33 @@ def main():
             start_thread.start()
             front_seq = [0]
 
+            # the captured front end (engine.FrontEndGraph): one hipGraph per shape bucket - here the single bucket (G clips of F frames,
+            # this r, this prompt structure, spare sequences B ..) - replayed once per group after four device-to-device copies of its inputs
+            fe = {"graph": None, "use": False, "launches": 0}
+            plan_vr = torch.stack([pl["vis_rows"] for pl in plans]) if args.front_graph else None
+            plan_ti = torch.stack([pl["text_ids"] for pl in plans]) if args.front_graph else None
+            plan_tr = torch.stack([pl["text_rows"] for pl in plans]) if args.front_graph else None
+
             def front_async(g):
                 t_host = time.perf_counter()
                 with torch.cuda.stream(sF):
-                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0 = torch.cuda.Event(enable_timing=True, blocking=True)      # a helper thread sleeps on it (start stamp)
                     e0.record(sF)
-                    vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
-                    ev_v = torch.cuda.Event(enable_timing=True)
-                    ev_v.record(sF)
-                    for j in range(G):
-                        eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
-                    ev_p = torch.cuda.Event(enable_timing=True)
-                    ev_p.record(sF)
-                    eng.prefill_stage(B, G, emb_all, L0)
+                    if fe["use"]:
+                        fe["graph"].load(pixels[g * G * F:(g + 1) * G * F], vis_rows=plan_vr[g * G:(g + 1) * G], text_ids=plan_ti[g * G:(g + 1) * G],
+                                         text_rows=plan_tr[g * G:(g + 1) * G])
+                        fe["graph"].launch()
+                        fe["launches"] += 1
+                        ev_v = ev_p = None
+                    else:
+                        vis = eng.vit_encode(pixels[g * G * F:(g + 1) * G * F], r)
+                        ev_v = torch.cuda.Event(enable_timing=True)
+                        ev_v.record(sF)
+                        for j in range(G):
+                            eng.project_splice(vis[j * F:(j + 1) * F], plan=plans[g * G + j], out=emb_all[j * Mseq:(j + 1) * Mseq])
+                        ev_p = torch.cuda.Event(enable_timing=True)
+                        ev_p.record(sF)
+                        eng.prefill_stage(B, G, emb_all, L0)
                     evf = torch.cuda.Event(enable_timing=True)
                     evf.record(sF)
                 if k_cal["on"]:
@@ -703,7 +732,7 @@ def main():
                             sC.wait_event(e1)
                             eng.slot_collect(g * G, G, first_dev[g], first_len[g])
                             first_host[g].copy_(first_dev[g, :, 0], non_blocking=True)
-                            e2 = torch.cuda.Event()
+                            e2 = torch.cuda.Event(blocking=True)
                             e2.record(sC)
                         host_q.put((t_host[0], t_host[1], e2))
                     # the chunk's decode is enqueued BEFORE the next front end (a few hundred launches on the host): both wait for
@@ -715,8 +744,27 @@ def main():
                     # wait out those steps (`commit_wait`, 34-39 ms of every TTFT).  Same steps, same kernels, same ids.
                     lead = (n - k1 if args.ttft_delay_steps < 0 else min(args.ttft_delay_steps, n - k1)) if k1 > 0 else 0
                     go = e1
+                    rest = n - k1 - lead
+                    # bounded run-ahead (TTFT runs from the SUBMISSION of a request): the chunk's LAST segment records `gate`
+                    # --ttft-gate-steps decode steps before its end; the next iteration submits its front end only once the device is there
+                    gate_at = max(0, args.ttft_gate_steps)
+                    last_seg = "rest" if rest > 0 else ("masked" if k1 > 0 else "lead")
+                    gate_next = [None]
+
+                    def decode_seg(steps, seg):
+                        if gate_on and seg == last_seg:
+                            pre = max(steps - gate_at, 0)
+                            if pre > 0:
+                                eng.decode(pre)
+                            gate_next[0] = torch.cuda.Event(blocking=True)      # the host SLEEPS on it (hipEventBlockingSync), it does not spin
+                            gate_next[0].record(torch.cuda.current_stream())
+                            if steps - pre > 0:
+                                eng.decode(steps - pre)
+                        else:
+                            eng.decode(steps)
+
                     if lead > 0:
-                        eng.decode(lead)
+                        decode_seg(lead, "lead")
                         go = torch.cuda.Event()
                         go.record(sD)
                     if k1 > 0:
@@ -727,7 +775,7 @@ def main():
                                 evm0.record(sDm)
                             eng.set_option("decode_half_grid", half_grid)   # half as many workgroups, twice the tiles each
                             try:
-                                eng.decode(k1)
+                                decode_seg(k1, "masked")
                             finally:                                        # a failed decode must not leave the ctx on the half grid
                                 eng.set_option("decode_half_grid", 0)
                             evm = torch.cuda.Event(enable_timing=k_cal["on"])
@@ -735,9 +783,15 @@ def main():
                             if k_cal["on"]:
                                 k_cal["dec_ev"].append((evm0, evm, k1))
                         sD.wait_event(evm)
-                    if n - k1 - lead > 0:
-                        eng.decode(n - k1 - lead)
+                    if rest > 0:
+                        decode_seg(rest, "rest")
                     sF.wait_event(go)
+                    if gate_on and gate_prev[0] is not None:
+                        t_w = time.perf_counter()
+                        gate_prev[0].synchronize()                          # the device is within `gate_at` steps of this group's commit
+                        if timed:
+                            host_enq["gate_wait_s"] = host_enq.get("gate_wait_s", 0.0) + time.perf_counter() - t_w
+                    gate_prev[0] = gate_next[0]
                     pending[0] = front_async((g + 1) % NG)
                     if args.sync_chunks:
                         sD.synchronize()
@@ -752,11 +806,41 @@ def main():
                 return o
 
             sF.wait_stream(sD)
+            gate_on = args.ttft_gate_steps >= 0
+            gate_prev = [None]
+            if args.front_graph:
+                from aurora_amd.engine import FrontEndGraph
+                t_cap = time.perf_counter()
+                with torch.cuda.stream(sF):                        # captured on the stream that replays it, with the front end's GEMM grid (gemm_max_wgs)
+                    fe["graph"] = FrontEndGraph(eng, G, F, v["image_size"], v["image_size"], r, plans[0], seq0=B, embeds=emb_all)
+                    fe["graph"].launch()                           # first replay (uploads the graph) outside every timed interval
+                sF.synchronize()
+                fe["capture_s"] = time.perf_counter() - t_cap
             pending[0] = front_async(0)
             k_cal["on"] = args.overlap_steps < 0 and sDm is not None      # measured during the warm-up cycle(s) below, applied after them
-        for _ in range(max(args.warmup - 1, 1 if overlap else 0)):  # overlap: the first front end above overlapped nothing
-            cycle(False, False)
+        n_warm = max(args.warmup - 1, 1 if overlap else 0)          # overlap: the first front end above overlapped nothing
+        for wi in range(n_warm):
+            # the FIRST warm-up cycle enqueues its front ends eagerly with per-stage events (the ViT / splice / prefill split of a serving
+            # TTFT, `ttft_stage_ms.serving`: events cannot be recorded inside the captured graph); every later cycle replays the graph
+            cycle(False, bool(overlap and fe["graph"] is not None and wi == 0))
+            if overlap and fe["graph"] is not None:
+                if wi == 0:
+                    stage_ev_eager = list(stage_ev)
+                    stage_ev.clear()
+                    lat_ev.clear()
+                fe["use"] = True
+        if overlap and fe["graph"] is not None and n_warm == 0:
+            fe["use"] = True
         fence()
+        if overlap:
+            start_q.join()                                         # the helper threads have stamped everything the warm-up cycles submitted
+            host_q.join()
+            submit_ttft.clear()
+            host_ttft.clear()
+            for k_ in ("enqueue_s", "enqueue_cpu_s", "gate_wait_s"):
+                host_enq[k_] = 0.0
+            host_enq["cycles"] = 0
+        stamps_before = eng.decode_stamps()[1] if stamp_layer >= 0 else 0
         if overlap and k_cal["on"]:
             k_cal["on"] = False
             t_front = float(np.median([a.elapsed_time(b) for a, b in k_cal["front_ev"][:-1]]))      # the last one ran beside nothing (fence)
@@ -777,19 +861,28 @@ def main():
         elapsed = time.perf_counter() - t_start
         host_enq["cpu_s"] = time.process_time() - cpu_start
         power = sampler.stop() if sampler else None
+        if stamp_layer >= 0:
+            us_, tot_ = eng.decode_stamps()
+            n_t = int(min(tot_ - stamps_before, len(us_)))
+            stamps_timed = us_[len(us_) - n_t:] if n_t > 0 else None
         # same clips in the same slots as the batch-mode step: batch-invariant kernels must give the same ids, every cycle
         assert all(o == batch_ref for o in outs), "continuous batching produced different captions than the batch-mode step"
         if overlap and args.gemm_cus <= 0:
             eng.set_option("gemm_max_wgs", 0)                      # the instrumented pass below runs alone on the whole GPU
         ttft_ms.extend(a.elapsed_time(b) for a, b in lat_ev for _ in range(G))
         if overlap and stage_ev:
-            med = lambda i, j: float(np.median([ev[i].elapsed_time(ev[j]) for ev in stage_ev]))
-            serving_split = {"vit_and_tome": med(0, 1), "projector_splice": med(1, 2), "prefill_layers": med(2, 3),
+            med = lambda i, j, evs=stage_ev: float(np.median([ev[i].elapsed_time(ev[j]) for ev in evs]))
+            inner = stage_ev_eager if fe["use"] else stage_ev       # events inside the front end exist for eagerly enqueued front ends only
+            serving_split = {"vit_and_tome": med(0, 1, inner) if inner else None, "projector_splice": med(1, 2, inner) if inner else None,
+                             "prefill_layers": med(2, 3, inner) if inner else None, "front_end": med(0, 3),
                              "commit_wait": med(3, 4), "lm_head_argmax_commit": med(4, 5), "total": med(0, 5),
                              "note": "medians over the timed cycles' groups of %d clips, device events: the front-end stream (16 CUs of every XCD, beside the "
                                      "masked decode) runs ViT + ToMe, projector + splice and the staged prefill layer stack; `commit_wait` is the time the "
                                      "finished front end waits for the decode stream to reach the group's boundary; the commit (decode stream) swaps the "
-                                     "page-table rows and produces the first tokens" % G}
+                                     "page-table rows and produces the first tokens" % G
+                                     + ("; the front end of a timed cycle is ONE hipGraph replay (`front_end`), so its inner split (vit_and_tome / "
+                                        "projector_splice / prefill_layers) comes from the first warm-up cycle, whose front ends were enqueued eagerly "
+                                        "with events between the stages" if fe["use"] else "")}
         if overlap:
             host_q.put(None)
             start_q.put(None)
@@ -926,14 +1019,23 @@ def main():
                        "decode_half_grid_on_masked_steps": bool(args.half_grid) if (continuous and overlap) else None,
                        "pipeline": "decode(batch i) || ViT+prefill(batch i+1) on two streams / two KV banks" if pipe else "none"},
             "overlap_steps_calibration": (k_cal["info"] if (continuous and overlap) else None),
-            "p50_ttft_ms": float(np.median(ttft_ms)) if ttft_ms else None,
+            # TTFT = submit -> first generated token id on host.  The overlapped schedule bounds the host's run-ahead
+            # (--ttft-gate-steps) and reports the host clock from the SUBMISSION of a group's front end to its first ids in pinned host
+            # memory; the device-event interval (what rounds 1-5 reported under this name) stays beside it
+            "p50_ttft_ms": (float(np.median(submit_ttft)) if (continuous and overlap and gate_on and submit_ttft) else (float(np.median(ttft_ms)) if ttft_ms else None)),
+            "p50_ttft_definition": ("host clock: submission of a group's front end (host call) -> its first token ids in pinned host memory; the host submits a "
+                                    "front end only when the device is within %d decode step(s) of the commit that precedes its start (bounded run-ahead)"
+                                    % max(args.ttft_gate_steps, 0)) if (continuous and overlap and gate_on and submit_ttft) else "device-event interval (see ttft_note)",
+            "p50_ttft_device_ms": float(np.median(ttft_ms)) if ttft_ms else None,
+            "p90_ttft_ms": (float(np.percentile(submit_ttft, 90)) if (continuous and overlap and gate_on and submit_ttft) else None),
             "power": power, "power_sampling": ("off" if not (rank == 0 and want_power) else (power or {}).get("how", "no samples")),
             "p50_ttft_host_ms": (float(np.median(host_ttft)) if (continuous and overlap and host_ttft) else None),
             "ttft_host_note": ("host clock from the moment a group's front end STARTS on the device (a helper thread waits for its first event) to its "
                                "first token ids sitting in pinned host memory (a side stream copies them after the commit; a second helper thread "
                                "waits for the copy), same cycles as the timed region.  p50_submit_to_first_token_host_ms starts the clock at the host "
-                               "call that SUBMITS the front end instead: this benchmark enqueues a whole cycle ahead of the device, so that figure "
-                               "is dominated by its own queue depth, not by the path" if (continuous and overlap) else None),
+                               "call that SUBMITS the front end instead (= p50_ttft_ms when the run-ahead is bounded, --ttft-gate-steps >= 0; with "
+                               "--ttft-gate-steps -1 the enqueue thread runs a cycle ahead of the device and that figure is its queue depth)"
+                               if (continuous and overlap) else None),
             "p50_submit_to_first_token_host_ms": (float(np.median(submit_ttft)) if (continuous and overlap and submit_ttft) else None),
             "ttft_note": (("device-event interval from the start of a group's front end (ViT + ToMe + projector + splice + prefill of its %d clips) to "
                            "its first tokens; a request arriving while a decode chunk is queued also waits for that chunk (<= %d steps here)" % (G, S // NG + 1)
@@ -956,6 +1058,11 @@ def main():
                          if "per_rank" in host_enq else None),
             "process_cpu_s_per_cycle": (host_enq["cpu_s"] / args.steps) if "cpu_s" in host_enq else None,
             "process_cpu_util": (host_enq["cpu_s"] / elapsed) if "cpu_s" in host_enq else None,
+            "gate_wait_s_per_cycle": (host_enq.get("gate_wait_s", 0.0) / host_enq["cycles"]) if host_enq["cycles"] else None,
+            "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe["graph"].nodes, "replays_per_cycle": NG,
+                           "capture_s": fe.get("capture_s"), "decode_graph_replays_per_cycle": S,
+                           "eager_launches_per_cycle_besides": "per group: 4 input copies, 2 result copies, page-table swap + 4 resets + first-token kernels of the commit"}
+                          if (continuous and overlap and fe["use"]) else ({"form": "eager launches"} if continuous else None)),
             "cores_allowed": len(aff), "pinned_to_gpu_numa_cores": pinned,
             "note": "enqueue = host wall time of the Python thread that issues a cycle's launches, up to (not including) the blocking read-back of "
                     "the ids; process_cpu = user + system seconds of the whole process (enqueue thread, the two TTFT helper threads, the power sampler) "
@@ -1047,6 +1154,18 @@ def main():
                                                    % (pmc_tag, pmc_build, lib_sha, "the same build" if pmc_build == lib_sha else "a different build"),
                                    "algorithmic_bytes_per_launch": alg,
                                    "avg_launch_us": avg_s * 1e6, "launches_timed": an, "how": how}
+            if stamps_timed is not None and len(stamps_timed):
+                # the same kernel INSIDE the timed loop: replayed from the captured step, beside the front ends, partly on the half-chip
+                # mask - two one-thread launches in the captured step stamp the device clock around layer `stamp_layer`'s attention launch
+                st = np.asarray(stamps_timed)
+                roof["decode_attn"].update({
+                    "frac_in_timed_loop": alg / (st.mean() * 1e-6) / 8e12, "achieved_in_timed_loop": alg / (st.mean() * 1e-6) / 1e9,
+                    "avg_launch_us_in_timed_loop": float(st.mean()),
+                    "in_timed_loop": {"steps_stamped": int(len(st)), "layer": stamp_layer, "p10_us": float(np.percentile(st, 10)),
+                                      "p50_us": float(np.percentile(st, 50)), "p90_us": float(np.percentile(st, 90)),
+                                      "how": "device constant-rate clock stored by two one-thread launches that bracket this layer's attention launch inside the "
+                                             "captured decode step (option decode_stamp_layer), every step of the timed cycles (the last %d kept); the interval "
+                                             "includes two kernel boundaries (~3 us); algorithmic bytes at the mean context of a generation" % len(st)}})
         if kn > 0:
             alg = 2 * mlp * d * 2 + B * d * 2 + B * mlp * 2           # gate+up rows fp16 + x in + h out
             avg_s = kms / kn * 1e-3

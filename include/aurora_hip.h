@@ -54,7 +54,8 @@ typedef struct aur_config {
     int32_t max_batch;          /* decode slots (batch rows of the decode step), <= 128 */
     int32_t max_ctx;            /* tokens per sequence (prompt + generated) */
     int32_t max_new_tokens;     /* output buffer width per slot */
-    int32_t page_tokens;        /* KV page size in tokens (multiple of 64) */
+    int32_t page_tokens;        /* KV page size in tokens: must be 64 (the decode attention's page pipeline is written for 64-token pages;
+                                 * aur_create rejects anything else - kept as a field so the KV layout stays self-describing) */
     int32_t use_graph;          /* 1: capture the decode step into a hipGraph */
     int32_t num_banks;          /* 1 or 2 generation banks (2: KV pool and per-batch state doubled, see aur_select_bank) */
     int32_t vit_native_image;   /* side of the square input the checkpoint's position table was trained for (config.image_size);
@@ -175,6 +176,31 @@ int aur_slot_state(aur_ctx* ctx, int32_t* lens_host, int32_t* finished_host, voi
  * without ever draining the stream (bench.py's steady-state latency point). */
 int aur_slot_collect(aur_ctx* ctx, int32_t slot0, int32_t nslots, int32_t* ids_dev, int32_t* lens_dev, void* stream);
 
+/* ---- captured front ends (the reference tree's serving engine captures one graph per shape bucket and copies the inputs into the
+ * graph's static buffers before every replay: src/sglang/python/sglang/srt/model_executor/cuda_graph_runner.py:163-279) ------------
+ * aur_graph_begin opens a hipGraph capture on `stream` (thread-local mode); every enqueue-only call of this ctx that follows on that
+ * stream from the same thread - aur_vit_encode(_hw), aur_project_splice, aur_llm_prefill / _batch / _stage / _commit, aur_slot_reset /
+ * _retire / _collect, the kernel-level entry points - is recorded instead of run; aur_graph_end instantiates the recording and returns
+ * a handle (>= 1) that aur_graph_launch replays with one call.  Pointers, shapes, KV sequence ids and the ctx's gemm_* knobs are frozen
+ * at capture time: a serving loop keeps one graph per (frames, input size, r, prompt structure, target sequences) bucket and copies
+ * each clip's pixels / ids into the bucket's staging buffers before the replay (aurora_amd/engine.py FrontEndGraph).  Calls that
+ * synchronise or re-capture (aur_get_outputs, aur_unfinished, aur_slot_state, aur_microbench, aur_decode_stamps_read, aur_begin_batch,
+ * aur_set_option, aur_finalize, aur_profile_enable) and aur_llm_decode (it replays its own graph) return AUR_ERR_STATE inside a capture
+ * without touching the runtime: the capture stays valid, and aur_graph_end - which must be called in any case - closes it.  A
+ * synchronising HIP call of the CALLER's own inside the capture invalidates it: aur_graph_end then returns AUR_ERR_HIP.  One capture at
+ * a time per ctx.  aur_graph_destroy: the caller guarantees no replay is still queued. */
+int aur_graph_begin(aur_ctx* ctx, void* stream);
+int aur_graph_end(aur_ctx* ctx, void* stream, int32_t* graph_out, int64_t* nodes_out);
+int aur_graph_launch(aur_ctx* ctx, int32_t graph, void* stream);
+int aur_graph_destroy(aur_ctx* ctx, int32_t graph);
+
+/* With option "decode_stamp_layer" = l (aur_set_option; -1 = off, the default) every decode step brackets layer l's attention launch
+ * with two one-thread launches that store the device's constant-rate clock: the kernel's duration in the loop the caller really runs
+ * (replayed from the graph, on whatever stream, beside whatever else) plus two kernel boundaries (~3 us).  Copies the intervals of the
+ * last min(cap, steps stamped, 4096) steps to us_out (microseconds, oldest first), their number to *n_out and the total number of
+ * stamped steps to *steps_total_out (may be NULL).  Synchronises the stream. */
+int aur_decode_stamps_read(aur_ctx* ctx, double* us_out, int32_t cap, int64_t* steps_total_out, int32_t* n_out, void* stream);
+
 /* ---- kernel-level entry points (parity tests, reuse by other callers) --------------------------- */
 /* One ToMe step on caller data: replaces bipartite_soft_matching + merge_wavg (tome.py:18-98,207-219;
  * call site aurora.py:746-747).  metric fp32 [frames, t, c]; x fp16 [frames, t, d]; size fp32 [frames, t]
@@ -216,7 +242,7 @@ int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
  * "dec_attn_local" 1 (default: on engines of 8-15 slots x 32 heads the splits of a (sequence, head) are the waves of one attention workgroup,
  * joined through LDS) / 0 (decode_attn_combine_kernel joins them; bitwise the same),
  * "dec_attn_pps" pages per
- * decode-attention split, "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
+ * decode-attention split, "decode_stamp_layer" (see aur_decode_stamps_read), "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
  * "gemm_nt_out" -1 (default: GEMM outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always),
  * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
  * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
