@@ -100,6 +100,8 @@ class AuroraCapEngine:
         self.proj_cfg = projector_settings(pc, vv["hidden_size"] if v else None, ll["hidden_size"] if l else None)
         c.proj_depth, c.proj_act = self.proj_cfg["depth"], _lib.ACT_BY_NAME[self.proj_cfg["hidden_act"]]
         self.spare_slots = spare_slots
+        self._front_graphs = {}                          # shape bucket -> FrontEndGraph (caption_stream's captured front ends), LRU order
+        self.front_graph_cap = 16
         self._bank_state = {0: (0, 0), 1: (0, 0)}        # bank -> (batch, max_new) for outputs()
         self._bank = 0
         self.c = c
@@ -142,6 +144,7 @@ class AuroraCapEngine:
     def close(self):
         if getattr(self, "ctx", None):
             torch.cuda.synchronize()
+            self._front_graphs = {}                                 # the graphs themselves die with the ctx
             self.L.aur_destroy(self.ctx)
             self.ctx = None
             self._masked = {}                                       # CU-masked streams are shared per process (streams.py): never destroyed
@@ -529,7 +532,7 @@ class AuroraCapEngine:
         return lens, fin
 
     def caption_stream(self, clips, token_kept_ratio: float, max_new_tokens: int, eos_id: Optional[int] = 2, slots: Optional[int] = None,
-                       check_every: int = 16, on_error=None, overlap: Optional[bool] = None, front_cus: int = 16):
+                       check_every: int = 16, on_error=None, overlap: Optional[bool] = None, front_cus: int = 16, front_graph: bool = True):
         """Continuous batching over an iterable of (pixel_values, input_ids): up to `slots` (default max_batch) captions are
         in flight; every `check_every` decode steps the finished slots are collected and re-filled with the next clips
         (ViT + projector + prefill into the free slot while the others keep their KV and state).  Yields (index, ids) in
@@ -541,7 +544,8 @@ class AuroraCapEngine:
         `streams.overlap_pays` whether a decode of that many slots is K / V-bound enough for it): the front ends of the NEXT clips run ahead on
         their own stream, restricted to `front_cus` CUs of every XCD, into the spare KV sequences while every slot keeps
         decoding (decode is HBM-bound, ViT + prefill MFMA-bound); a freed slot takes over a prepared clip's pages at the next
-        check (`prefill_commit`).  Same ids either way."""
+        check (`prefill_commit`).  front_graph (overlapped mode): each clip's front end is one hipGraph replay, captured per shape
+        bucket on first use (`_front_end_replay`); False = ~600 eager launches per clip.  Same ids either way."""
         B = self.max_batch if slots is None else slots
         if not 1 <= B <= self.max_batch:
             raise ValueError(f"slots={B} for an engine built with max_batch={self.max_batch}")
@@ -550,7 +554,8 @@ class AuroraCapEngine:
         if overlap:
             if self.spare_slots < 1:
                 raise ValueError("caption_stream(overlap=True) needs an engine built with spare_slots >= 1")
-            yield from self._caption_stream_overlapped(clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus)
+            yield from self._caption_stream_overlapped(clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus,
+                                                       front_graph)
             return
         self.begin_batch(B, max_new_tokens, eos_id)
         for s in range(B):
@@ -598,7 +603,42 @@ class AuroraCapEngine:
                                        shared_cu_masked_stream(32 - front_cus, from_top=True, device=self.dev))
         return self._masked[front_cus]
 
-    def _caption_stream_overlapped(self, clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus):
+    def _front_end_replay(self, px: torch.Tensor, ids: List[int], r: int, seq: int):
+        """ViT + ToMe + projector / splice + staged prefill of ONE clip into KV sequence `seq` as a single hipGraph replay on torch's
+        current stream.  Graphs are captured per shape bucket - (frames, H, W, r, prompt structure, seq) - on first use and kept (at most
+        `front_graph_cap`, least recently used evicted): the per-bucket capture of the reference tree's serving engine
+        (src/sglang/python/sglang/srt/model_executor/cuda_graph_runner.py:163-279).  Returns (embeds, seq_len) for `prefill_commit`;
+        `embeds` is the bucket's static buffer: the caller orders the next replay of the same bucket (same `seq`) after that commit."""
+        if px.dim() != 4 or px.shape[1] != self.v.get("num_channels", 3):
+            raise ValueError(f"pixel_values must be [frames, {self.v.get('num_channels', 3)}, H, W], got {tuple(px.shape)}")
+        F, H, W = int(px.shape[0]), int(px.shape[-2]), int(px.shape[-1])
+        t0 = (H // self.v["patch_size"]) * (W // self.v["patch_size"]) + 1
+        if F < 1 or F > self.c.max_frames or t0 < 2 or t0 > (self.max_image // self.v["patch_size"]) ** 2 + 1:
+            raise ValueError(f"clip of {F} frames of {H}x{W} outside this engine (max_frames {self.c.max_frames}, max_image {self.max_image})")
+        n_kept = tokens_at_layer(t0, r, self.v["num_hidden_layers"] - 1) - 1
+        plan = self.splice_plan(ids, F, n_kept)
+        if plan["seq_len"] < 1 or plan["seq_len"] + self._max_new > self.c.max_ctx:
+            raise ValueError(f"prompt of {plan['seq_len']} positions + {self._max_new} new tokens exceeds max_ctx {self.c.max_ctx}")
+        key = (F, H, W, r, seq, plan["seq_len"], plan["used"], plan["nvis"], plan["ntext"])
+        cache = self._front_graphs
+        fg = cache.pop(key, None)
+        if fg is None:
+            while len(cache) >= self.front_graph_cap:             # evict the least recently used bucket once its last replay has run
+                _, old = next(iter(cache.items()))
+                cache.pop(next(iter(cache)))
+                if old._last is not None:
+                    old._last.synchronize()
+                old.close()
+            fg = FrontEndGraph(self, 1, F, H, W, r, plan, seq0=seq)
+            fg._last = None
+        cache[key] = fg                                           # most recently used last
+        fg.load(self._h(px), [plan])
+        fg.launch()
+        fg._last = torch.cuda.Event()
+        fg._last.record(torch.cuda.current_stream(self.dev))
+        return fg.embeds, plan["seq_len"]
+
+    def _caption_stream_overlapped(self, clips, token_kept_ratio, max_new_tokens, eos_id, B, check_every, on_error, front_cus, front_graph=True):
         from collections import deque
         sD = torch.cuda.current_stream(self.dev)
         sF, sDm = self._masked_streams(front_cus)
@@ -665,9 +705,12 @@ class AuroraCapEngine:
                             if seq in reusable:
                                 sF.wait_event(reusable.pop(seq))
                             r = self.tome_r(token_kept_ratio, px.shape[-2], px.shape[-1])
-                            vis = self.vit_encode(px, r)
-                            emb, L = self.project_splice(vis, list(ids))
-                            self.prefill_stage(seq, 1, emb, L)    # argument checks come before any enqueue
+                            if front_graph:
+                                emb, L = self._front_end_replay(px, list(ids), r, seq)      # one hipGraph replay per clip (captured per shape bucket)
+                            else:
+                                vis = self.vit_encode(px, r)
+                                emb, L = self.project_splice(vis, list(ids))
+                                self.prefill_stage(seq, 1, emb, L)    # argument checks come before any enqueue
                             ev = torch.cuda.Event()
                             ev.record(sF)
                         staged.append((idx, seq, emb, L, ev))

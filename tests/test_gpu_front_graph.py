@@ -148,3 +148,27 @@ def test_decode_stamps_time_the_step_without_changing_a_token():
             eng.set_option("decode_stamp_layer", 99)
     finally:
         eng.close()
+
+
+def test_caption_stream_replays_one_graph_per_shape_bucket():
+    """The product's overlapped stream (engine.caption_stream on an engine with spare KV sequences) submits each clip's front end as one
+    graph replay; buckets are captured on first use, evicted least-recently-used beyond `front_graph_cap`; ids equal the eager stream's
+    and each clip's own."""
+    from tests.test_gpu_caption_batch import clips
+    eng = build(3, 2, 16)
+    try:
+        cs = clips(12, 21)
+        alone = [eng.caption_ids(px, ids, 0.5, 16, eos_id=None) for px, ids in cs]
+        eager = dict(eng.caption_stream(cs, 0.5, 16, eos_id=None, check_every=4, front_graph=False))
+        assert not eng._front_graphs
+        got = dict(eng.caption_stream(cs, 0.5, 16, eos_id=None, check_every=4))
+        assert got == eager == {i: alone[i] for i in range(12)}
+        n_buckets = len(eng._front_graphs)
+        assert 2 <= n_buckets <= eng.front_graph_cap
+        again = dict(eng.caption_stream(cs, 0.5, 16, eos_id=None, check_every=5))      # every bucket is replayed, none re-captured
+        assert again == eager and len(eng._front_graphs) == n_buckets
+        eng.front_graph_cap = 2                                    # eviction on nearly every clip: still the same ids
+        assert dict(eng.caption_stream(cs, 0.5, 16, eos_id=None, check_every=4)) == eager
+        assert len(eng._front_graphs) <= n_buckets
+    finally:
+        eng.close()
