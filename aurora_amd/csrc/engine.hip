@@ -325,6 +325,12 @@ extern "C" int aur_create(const aur_config* cfg, aur_ctx** out) {
     if (g.max_batch < 1 || g.max_batch > AUR_MAX_BATCH) return aur_fail(nullptr, AUR_ERR_ARG, "max_batch must be in [1, %d]", AUR_MAX_BATCH);
     if (g.page_tokens != 64) return aur_fail(nullptr, AUR_ERR_ARG, "page_tokens must be 64 (the decode attention's page pipeline is written for 64-token pages)");
     if (g.vit_image % g.vit_patch) return aur_fail(nullptr, AUR_ERR_ARG, "image size must be a multiple of the patch size");
+    {   // the ToMe step's limits (tome.hip launch_tome_step), checked here so that an out-of-range ViT fails at create time, not at the first encode
+        const int64_t t0 = (int64_t)(g.vit_image / g.vit_patch) * (g.vit_image / g.vit_patch) + 1;
+        if (g.vit_hidden > 2048) return aur_fail(nullptr, AUR_ERR_ARG, "vit_hidden %d exceeds 2048 (token-merge kernel: one row of at most 2048 features per wave)", g.vit_hidden);
+        if (g.vit_hidden / g.vit_heads > 128) return aur_fail(nullptr, AUR_ERR_ARG, "vit head_dim %d exceeds 128 (token-merge metric: at most 128 channels)", g.vit_hidden / g.vit_heads);
+        if ((t0 + 1) / 2 > 4096) return aur_fail(nullptr, AUR_ERR_ARG, "vit_image %d / patch %d gives %lld tokens per frame; the token-merge select kernel ranks at most 4096 = ceil(t / 2) of them", g.vit_image, g.vit_patch, (long long)t0);
+    }
     if (g.vit_native_image < 0 || g.vit_native_image > g.vit_image || g.vit_native_image % g.vit_patch)
         return aur_fail(nullptr, AUR_ERR_ARG, "vit_native_image must be 0 or a multiple of the patch size <= vit_image");
     {
@@ -508,6 +514,8 @@ extern "C" int aur_pack_linear(aur_ctx* ctx, const void* w, int32_t n_src, int32
 // its name instead of by kernel name only.  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so)
 // when AURORA_ROCTX=1 is set - the product library has no link-time dependency on a profiler, and without the variable a range costs one
 // predictable branch.  Ranges bracket the host-side ENQUEUE of a stage (what roctx measures); the device time is in the kernel trace.
+// A ctx is driven by ONE host thread at a time (include/aurora_hip.h: "calls on one ctx are not re-entrant"): the open range of a stage name is state of the ctx,
+// keyed by (name, stream), so the same stage enqueued on two streams by that thread (a front end beside the decode) keeps two ranges apart.
 // Ranges are START / STOP ranges with ids (not the push / pop stack): an entry point that fails between stage_begin and stage_end
 // (every CK() is an early return) leaves ONE unclosed range, which the next stage_begin of that name closes - the nesting of later
 // stages cannot be skewed.
@@ -529,9 +537,14 @@ static const Roctx& roctx() {
     static Roctx r;          // read-only after its thread-safe initialisation
     return r;
 }
+static std::string range_key(const char* name, hipStream_t s) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "%s@%p", name, (void*)s);
+    return buf;
+}
 static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
     if (roctx().start) {
-        StageTimer& tr = c->timers[name];
+        StageTimer& tr = c->timers[range_key(name, s)];
         if (tr.range_open) roctx().stop(tr.range_id);       // left open by a call that failed mid-stage
         tr.range_id = roctx().start(name);
         tr.range_open = true;
@@ -553,7 +566,7 @@ static void stage_begin(aur_ctx* c, const char* name, hipStream_t s) {
 }
 static void stage_end(aur_ctx* c, const char* name, hipStream_t s) {
     if (roctx().stop) {
-        StageTimer& tr = c->timers[name];
+        StageTimer& tr = c->timers[range_key(name, s)];
         if (tr.range_open) roctx().stop(tr.range_id);
         tr.range_open = false;
     }
@@ -813,6 +826,8 @@ extern "C" int aur_tome_step(aur_ctx* ctx, const float* metric, const void* x, c
     const int64_t ta = (t + 1) / 2;
     // scratch must fit the ctx workspace regions sized for the configured ViT
     if (c > 128) return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: at most 128 metric channels (got %d)", c);
+    if (ta > 4096) return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: ceil(t / 2) = %lld exceeds 4096 (the select kernel ranks one frame's A tokens in one workgroup)", (long long)ta);
+    if (d > 2048) return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: d = %d exceeds 2048 (a merge workgroup holds one row of at most 2048 features per wave)", d);
     if ((int64_t)frames * tome_mfrag_floats(t, c) > (int64_t)ctx->cfg.max_frames * tome_mfrag_floats(ctx->v_t0, ctx->v_hd) || (int64_t)frames * ta > (int64_t)ctx->cfg.max_frames * ((ctx->v_t0 + 1) / 2) ||
         (int64_t)frames * rup(t, 32) * d > (int64_t)ctx->cfg.max_frames * ctx->v_t0pad * ctx->cfg.vit_hidden)
         return aur_fail(ctx, AUR_ERR_ARG, "aur_tome_step: problem larger than the workspace configured at aur_create");

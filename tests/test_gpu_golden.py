@@ -155,3 +155,47 @@ def test_g15_projector_variants_through_the_engine(name):
         assert rel_l2(out, want) < 5e-3 and (out - want).abs().max().item() <= 2e-2 * want.abs().max().item()
     finally:
         eng.close()
+
+
+def test_g9b_hf_llama_head_dim_128_long_positions_through_the_kernels():
+    """G9b: HF LlamaForCausalLM (the model inference.py:47-51 decodes with) at head_dim 128 under linear RoPE x4 - the prefill kernels'
+    first-token logits against HF's own rows at prompt lengths 8 / 2101 / 2108 / 6851 / 6874 (RoPE in the QKV epilogue at the positions
+    cfg2's prefill and cfg5's context reach, causal MFMA attention over 108 key blocks), and the decode kernels over a 6850-position paged
+    KV against the oracle that tests/test_oracle_golden.py holds to the same fixture."""
+    from oracle import aurora_oracle as O
+    from aurora_amd.engine import AuroraCapEngine
+    from tests.parity_bounds import LOGIT_TOL
+    from tests.test_gpu_llm import padded
+    from tests.test_oracle_golden import llama_weights
+    g = golden("g9b_llama_hd128_long.npz")
+    lw, cfg = llama_weights(g)
+    lw = {k: (v.float() if torch.is_tensor(v) else [{kk: vv.float() for kk, vv in l.items()} for l in v]) for k, v in lw.items()}
+    ids = tt(g["ids"]).long()
+    rows = g["rows"].tolist()
+    want = tt(g["logits"])
+    scale = want.abs().max().item()
+    eng = AuroraCapEngine({"vit": None, "llm": cfg}, {"llm": lw}, max_frames=1, max_batch=1, max_ctx=6912, max_new_tokens=16)
+    try:
+        x = lw["embed_tokens.weight"][ids]                                    # fp16-representable rows
+        for L in (8, 2101, 2108, 6851, 6874):
+            eng.begin_batch(1, 16, None)
+            eng.prefill(0, padded(x[:L]), L)
+            got = eng.logits()[0].cpu()
+            observe("golden/g9b_prefill_logits_vs_hf_over_scale", (got - want[rows.index(L - 1)]).abs().max().item() / scale, LOGIT_TOL)
+        # decode at long positions: 12 greedy steps after a 6850-row prefill, teacher-forced oracle logits on the GPU's own tokens
+        eng.begin_batch(1, 13, None)
+        eng.prefill(0, padded(x[:6850]), 6850)
+        logits = [eng.logits()[0].cpu()]
+        for _ in range(12):
+            eng.decode(1)
+            logits.append(eng.logits()[0].cpu())
+        out = eng.outputs()[0]
+        assert len(out) == 13
+        full = torch.cat([x[:6850], lw["embed_tokens.weight"][torch.tensor(out[:-1])]], 0)
+        h, _ = O.llama_forward(full, lw, cfg, None, 0)
+        ref = torch.nn.functional.linear(h[6849:], lw["lm_head.weight"])
+        for i in range(13):
+            observe("golden/g9b_decode_logits_at_6850_over_scale", (logits[i] - ref[i]).abs().max().item() / ref.abs().max().item(), LOGIT_TOL)
+            assert int(torch.argmax(logits[i])) == out[i]
+    finally:
+        eng.close()

@@ -267,12 +267,25 @@ def test_observe_records_the_worst_value_and_asserts_the_bound(tmp_path, monkeyp
     util.observe("k/le", 0.4, 1.0)
     util.observe("k/ge", 9, 5, at_least=True)
     util.observe("k/ge", 6, 5, at_least=True)
-    assert util._OBSERVED["k/le"] == {"worst": 0.7, "n": 3, "bound": 1.0, "kind": "<="}
-    assert util._OBSERVED["k/ge"] == {"worst": 6.0, "n": 2, "bound": 5.0, "kind": ">="}
+    assert util._OBSERVED["k/le"] == {"worst": 0.7, "n": 3, "bound": 1.0, "kind": "<=", "shared": 1.0}
+    assert util._OBSERVED["k/ge"] == {"worst": 6.0, "n": 2, "bound": 5.0, "kind": ">=", "shared": 5.0}
     with pytest.raises(AssertionError):
         util.observe("k/le", 1.5, 1.0)
     with pytest.raises(AssertionError):
         util.observe("k/ge", 4, 5, at_least=True)
+    # a comparison with its own entry is held to the tighter of the two bounds (tests/parity_bounds.PER_COMPARISON)
+    from tests import parity_bounds as PB
+    monkeypatch.setitem(PB.PER_COMPARISON, "k/own", 0.5)
+    monkeypatch.setitem(PB.PER_COMPARISON, "k/own_ge", 7)
+    assert util.observe("k/own", 0.4, 1.0) == 0.4 and util._OBSERVED["k/own"]["bound"] == 0.5 and util._OBSERVED["k/own"]["shared"] == 1.0
+    with pytest.raises(AssertionError):
+        util.observe("k/own", 0.6, 1.0)
+    util.observe("k/own", 0.05, 0.1)                              # the shared constant wins when IT is tighter
+    with pytest.raises(AssertionError):
+        util.observe("k/own", 0.2, 0.1)
+    util.observe("k/own_ge", 7, 5, at_least=True)
+    with pytest.raises(AssertionError):
+        util.observe("k/own_ge", 6, 5, at_least=True)
     # flush merges into an existing file of the same run
     root = tmp_path / "repo"
     (root / "tests").mkdir(parents=True)

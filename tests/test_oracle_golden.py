@@ -206,6 +206,37 @@ def test_g9_llama_greedy_and_logits():
     np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-3, atol=2e-4)
 
 
+def test_g9b_llama_head_dim_128_at_long_positions():
+    """G9b (VERDICT r5 next #7 ii): HF LlamaForCausalLM - the model inference.py:47-51 decodes with - at the path's head_dim (128) and
+    positions (prefill rows around 2100, the long-KV config's 6.9 k) under linear RoPE scaling x4.  The oracle's prefill form must
+    reproduce HF's logits at every kept row, and its KV-cache form (prefill 6850 positions, then one position per call, as generate
+    does) must reproduce the last 24 - the form the 7B-width GPU tests compare the kernels with."""
+    g = golden("g9b_llama_hd128_long.npz")
+    lw, cfg = llama_weights(g)
+    lw = {k: (v.float() if torch.is_tensor(v) else [{kk: vv.float() for kk, vv in l.items()} for l in v]) for k, v in lw.items()}
+    assert cfg["hidden_size"] // cfg["num_attention_heads"] == 128 and cfg["rope_factor"] == 4.0
+    ids = tt(g["ids"]).long()
+    rows = g["rows"].tolist()
+    assert rows[-1] == len(ids) - 1 == 6873
+    x = lw["embed_tokens.weight"][ids]
+    h, _ = O.llama_forward(x, lw, cfg, None, 0)
+    logits = torch.nn.functional.linear(h[rows], lw["lm_head.weight"])
+    scale = float(np.abs(g["logits"]).max())
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-3, atol=2e-4 * scale)
+    # KV-cache form at long positions
+    h0, kv = O.llama_forward(x[:6850], lw, cfg, None, 0)
+    step = []
+    for t in range(6850, 6874):
+        ht, kv = O.llama_forward(x[t:t + 1], lw, cfg, kv, t)
+        step.append(torch.nn.functional.linear(ht, lw["lm_head.weight"])[0])
+    np.testing.assert_allclose(torch.stack(step).numpy(), g["logits"][16:], rtol=1e-3, atol=2e-4 * scale)
+    # a restatement with the wrong scaling or the interleaved rotation would be far outside these bounds: the rows are sensitive to RoPE
+    bad = dict(cfg, rope_factor=1.0)
+    hb, _ = O.llama_forward(x[:2108], lw, bad, None, 0)
+    lb = torch.nn.functional.linear(hb[rows[8:16]], lw["lm_head.weight"]).numpy()
+    assert np.abs(lb - g["logits"][8:16]).max() > 20 * 2e-4 * scale
+
+
 def test_process_text_and_prompt():
     text = O.build_prompt("Describe the video in detail.", 3)
     assert text == "USER: <image> <image> <image>\nDescribe the video in detail. ASSISTANT:"

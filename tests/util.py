@@ -133,9 +133,12 @@ _OBSERVED = {}
 
 
 def observe(key, value, bound, at_least=False):
-    """assert value <= bound (or >= bound with at_least) and remember the worst value seen under `key`"""
+    """assert value <= bound (or >= bound with at_least) - `bound` is the shared constant; the comparison's own entry in
+    tests/parity_bounds.PER_COMPARISON wins when it is tighter - and remember the worst value seen under `key`"""
     value = float(value)
-    rec = _OBSERVED.setdefault(key, {"worst": value, "n": 0, "bound": float(bound), "kind": ">=" if at_least else "<="})
+    from tests.parity_bounds import bound_for
+    shared, bound = float(bound), bound_for(key, bound, at_least)      # the comparison's own bound when it is tighter than the shared constant
+    rec = _OBSERVED.setdefault(key, {"worst": value, "n": 0, "bound": float(bound), "kind": ">=" if at_least else "<=", "shared": shared})
     rec["n"] += 1
     rec["worst"] = min(rec["worst"], value) if at_least else max(rec["worst"], value)
     rec["bound"] = float(bound)
