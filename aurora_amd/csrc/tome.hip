@@ -98,7 +98,18 @@ __global__ __launch_bounds__(1024) void tome_prep_kernel(KvLayout kv, const floa
                 const half_t* p0 = page + kfrag_off(kv, 0, tok >> 4, blk) + fl * 8;
                 const int64_t hstride = kfrag_off(kv, 1, 0, 0) - kfrag_off(kv, 0, 0, 0);
                 int h = 0;
-                for (; h + 4 <= kv.heads; h += 4) {                   // four independent loads in flight; summed in head order
+                // sixteen, then four independent 16-byte loads in flight per thread; summed in head order whatever the batching (round 6: with
+                // four in flight the launch ran at 1.4 TB/s - 72 MB of K fragments in 50 us at 32 frames - a latency-bound read)
+                for (; h + 16 <= kv.heads; h += 16) {
+                    h8 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = *(const h8*)(p0 + (h + u) * hstride);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += (float)v[u][j];
+                }
+                for (; h + 4 <= kv.heads; h += 4) {
                     h8 v[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(p0 + (h + u) * hstride);

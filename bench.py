@@ -341,6 +341,24 @@ def child_point(flags, timeout=1200):
         return None
 
 
+def thread_cpu_seconds():
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc/self/task): who burns the host while the GPU works"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def sleep_wait(ev, dt: float = 0.0005):
     """Wait for a HIP event WITHOUT spinning: hipEventSynchronize burns a core for the whole wait (also with hipEventBlockingSync on this
     runtime: measured 8.8 of 9.1 s of thread CPU time per cycle), and on an 8-rank host every rank has three such waiters."""
@@ -864,6 +882,7 @@ def main():
         sampler = PowerSampler(local).start() if (rank == 0 and want_power) else None
         t_start = time.perf_counter()
         cpu_start = time.process_time()
+        thr0 = thread_cpu_seconds()
         outs = []
         for _ in range(args.steps):
             out = cycle(False, True)
@@ -871,6 +890,8 @@ def main():
         fence()
         elapsed = time.perf_counter() - t_start
         host_enq["cpu_s"] = time.process_time() - cpu_start
+        thr1 = thread_cpu_seconds()
+        host_enq["threads"] = sorted(((n, round((c - thr0.get(t, (n, 0.0))[1]) / args.steps, 3)) for t, (n, c) in thr1.items()), key=lambda x: -x[1])[:6]
         power = sampler.stop() if sampler else None
         if stamp_layer >= 0:
             us_, tot_ = eng.decode_stamps()
@@ -1069,6 +1090,7 @@ def main():
                          if "per_rank" in host_enq else None),
             "process_cpu_s_per_cycle": (host_enq["cpu_s"] / args.steps) if "cpu_s" in host_enq else None,
             "process_cpu_util": (host_enq["cpu_s"] / elapsed) if "cpu_s" in host_enq else None,
+            "busiest_threads_cpu_s_per_cycle": host_enq.get("threads"),
             "gate_wait_s_per_cycle": (host_enq.get("gate_wait_s", 0.0) / host_enq["cycles"]) if host_enq["cycles"] else None,
             "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe["graph"].nodes, "replays_per_cycle": NG,
                            "capture_s": fe.get("capture_s"), "decode_graph_replays_per_cycle": S,
