@@ -1,10 +1,6 @@
 """Build libaurora_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m aurora_amd.build [--force] [--labs | --sanitize | --ubsan | --device-asan]
-
---labs builds libaurora_hip_labs.so with -DAUR_LABS: the product sources plus the lab-only kernel variants (gemm256.hip G2Lab, the
-round-3 inline-asm split-K hand-over) that tools/cumask/*_lab.py and tools/gpu/soak_fused_reduce.sh select through AURORA_HIP_SO.
-The product library contains none of them.
+    python -m aurora_amd.build [--force] [--sanitize | --ubsan | --device-asan]
 
 The shared library has a plain C ABI (include/aurora_hip.h) and no torch / python dependency.
 """
@@ -49,7 +45,6 @@ def needs_build(out: str = OUT) -> bool:
 # the shared ASan runtime so that an un-instrumented python can load it with LD_PRELOAD=<asan_runtime()>.  tests/test_asan_host.py.
 OUT_ASAN = os.path.join(HERE, "libaurora_hip_asan.so")
 OUT_UBSAN = os.path.join(HERE, "libaurora_hip_ubsan.so")        # UBSan alone: no preload, coexists with the HIP runtime on a GPU box
-OUT_LABS = os.path.join(HERE, "libaurora_hip_labs.so")          # -DAUR_LABS: lab kernel variants for tools/ only
 # Device-side AddressSanitizer: host AND gfx950 code instrumented; needs an xnack+ code object, a GPU
 # running with HSA_XNACK=1 and the ASan runtime preloaded.  tools/gpu/device_asan.sh tries it over the cross-workgroup hand-over tests.
 OUT_DASAN = os.path.join(HERE, "libaurora_hip_dasan.so")
@@ -69,18 +64,17 @@ def asan_runtime(name: str = "asan") -> str:
 
 def build(force: bool = False, verbose: bool = True, sanitize=False) -> str:
     """sanitize: False (the product), True / "asan" (ASan + UBSan on the host code), "ubsan" (UBSan only, traps made fatal),
-    "labs" (the product flags + -DAUR_LABS)"""
+    "dasan" (device-side ASan)"""
     ub = sanitize == "ubsan"
-    labs = sanitize == "labs"
     dasan = sanitize == "dasan"
-    out = OUT_DASAN if dasan else OUT_LABS if labs else OUT_UBSAN if ub else (OUT_ASAN if sanitize else OUT)
-    san = SAN_DEV if dasan else [] if labs else SAN_UB if ub else SAN
+    out = OUT_DASAN if dasan else OUT_UBSAN if ub else (OUT_ASAN if sanitize else OUT)
+    san = SAN_DEV if dasan else SAN_UB if ub else SAN
     if not force and not needs_build(out):
         return out
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build_dasan" if dasan else "build_labs" if labs else ("build_ubsan" if ub else "build_asan") if sanitize else "build")
+    objdir = os.path.join(HERE, "build_dasan" if dasan else ("build_ubsan" if ub else "build_asan") if sanitize else "build")
     os.makedirs(objdir, exist_ok=True)
-    common = COMMON + ["-DAUR_LABS"] if labs else [c if c != "-O3" else "-O1" for c in COMMON] + san if sanitize else COMMON
+    common = [c if c != "-O3" else "-O1" for c in COMMON] + san if sanitize else COMMON
     arch = "--offload-arch=gfx950:xnack+" if dasan else "--offload-arch=gfx950"
     common = [arch if c == "--offload-arch=gfx950" else c for c in common]
 
@@ -106,4 +100,4 @@ def build(force: bool = False, verbose: bool = True, sanitize=False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, sanitize="dasan" if "--device-asan" in sys.argv else "labs" if "--labs" in sys.argv else "ubsan" if "--ubsan" in sys.argv else ("--sanitize" in sys.argv))
+    build(force="--force" in sys.argv, sanitize="dasan" if "--device-asan" in sys.argv else "ubsan" if "--ubsan" in sys.argv else ("--sanitize" in sys.argv))

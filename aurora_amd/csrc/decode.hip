@@ -377,7 +377,6 @@ struct SkxGeom {
     int S;                  // k splits (gridDim.y); > 1 only for SK_ROW
     float* part;            // SK_ROW split-K partials, lane-linear [S][N16][NB][64][4]
     int* cnt;               // SK_ROW: arrival counter per tile (fused reduce), nullptr = skinny_row_reduce_kernel follows
-    int handover;           // AUR_LABS builds only: 2 = the round-3 inline-asm partial stores (soak script)
 };
 
 // 16-byte agent-scope accesses of the split-K hand-over (a tile's S workgroups may sit on different XCDs, whose L2s are not coherent for
@@ -392,7 +391,7 @@ struct SkxGeom {
 //     global_store_dwordx4 v[18:19], v[10:13], off sc1 ; s_mov_b64 s[0:1], 0x400 ; v_lshl_add_u64 v[10:11], v[18:19], 0, s[0:1]
 // - the next store's address computed INTO the previous store's data registers one state later.  Alone the store unit has read its data by
 // then; with the memory pipeline backed up beside a front end it sometimes has not, and a partial goes out with two dwords of an
-// address in it.  The protocol (counter, sc1, drain) was sound.  AUR_LABS builds keep that form as hand-over 2 for the soak script.
+// address in it.  The protocol (counter, sc1, drain) was sound (the asm form and its soak script are in the history up to commit 282d3cc; profiles/r04_fused_reduce_soak.log).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "the split-K hand-over relies on gfx950 sc1 semantics"
 #endif
@@ -406,10 +405,6 @@ __device__ __forceinline__ void st_agent16(__amdgpu_buffer_rsrc_t r, unsigned by
 __device__ __forceinline__ f4 ld_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
-#ifdef AUR_LABS
-// the round-3 form, kept for tools/gpu/soak_fused_reduce.sh only: no wait state after the store (see above)
-__device__ __forceinline__ void st_agent16_r03(float* p, const f4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-#endif
 
 template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
 __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(SkinnyArgs a, SkxGeom gm) {
@@ -607,16 +602,8 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
                 if (p == 0) {
                     gather(t * KS, 0, one[0]);
                     const unsigned off0 = (unsigned)((((s * N16 + tile) * NB) * 64 + lane) * 16);
-#ifdef AUR_LABS
-                    if (gm.handover == 2) {
 #pragma unroll
-                        for (int nb = 0; nb < NBPV; ++nb) st_agent16_r03(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4, one[0][nb]);
-                    } else
-#endif
-                    {
-#pragma unroll
-                        for (int nb = 0; nb < NBPV; ++nb) st_agent16(prs, off0 + nb * 1024, one[0][nb]);
-                    }
+                    for (int nb = 0; nb < NBPV; ++nb) st_agent16(prs, off0 + nb * 1024, one[0][nb]);
                     // the partial has reached the coherence point before the arrival is counted.  An asm wait on purpose: hipcc may
                     // drop its own vmcnt(0) ahead of an atomic when its scoreboard is empty (guide, Guideline 16 pitfall 12)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -782,7 +769,6 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             // there, o 18.9 -> 18.0 us, down 31.5 -> 29.4 us incl. the reduce, but neutral in the engine - 19.3 / 30.1 us either way - and
             // rocprofv3's counter mode crashed in this launch with that instantiation: kept as it was)
             gm.cnt = a.row_cnt;
-            gm.handover = a.row_handover;
             hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
             if (e != hipSuccess || gm.cnt != nullptr) return e;
             hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);
@@ -820,7 +806,8 @@ static hipError_t launch_skinny_nb(const SkinnyArgs& a, hipStream_t s) {
         case SK_ROW:
             // few output tiles (N = hidden): 8 waves per workgroup double the loads in flight per CU
             // (round 5: 16 waves on the o projection at 1 and 8 slots: 7.67 us against 7.55 with 8)
-            if (a.waves == 8 && (a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8, NB>(a, s);
+            // (4 waves measured twice, rounds 2 and 4: slower on every shape; K % 256 != 0 keeps them)
+            if ((a.K & 255) == 0) return launch_skinny_t<1, SK_ROW, 8, NB>(a, s);
             return launch_skinny_t<1, SK_ROW, 4, NB>(a, s);
         case SK_LOGITS: return launch_skinny_t<1, SK_LOGITS, 4, NB>(a, s);
         case SK_SILU_MUL: return launch_skinny_t<2, SK_SILU_MUL, 4, NB>(a, s);

@@ -77,16 +77,16 @@ struct aur_ctx {
     int32_t* ptab_rw() { return const_cast<int32_t*>(ptab_cur); }
     // generation state
     int batch = 0, max_new = 0, eos = -1, nsplit = 1, pps = 1;
-    int row_waves = 8, last_prefill_len = 0, mb_nseq = 1;                         // tuning knobs (aur_set_option)
+    int last_prefill_len = 0, mb_nseq = 1;                         // tuning knobs (aur_set_option)
     int decode_half = 0;             // 1: the next aur_llm_decode calls target a stream that owns half of the CUs (own hipGraph)
-    int gemm_mode = 1, gemm_max_wgs = 0, gemm_wide = 1, gemm_tile_order = 1, gemm_tail_split = 1, gemm_lab = 0, prune_last = 1, gemm_nt_out = -1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
+    int gemm_mode = 1, gemm_max_wgs = 0, gemm_tail_split = 1, prune_last = 1, gemm_nt_out = -1;                           // GEMM knobs: per ctx, copied into GemmArgs at every launch
     int skinny_variant = 0, row_split_min_k = 8192;                             // decode projections: x through LDS (engines of > 32 slots)
     int skinny_variant_wide = 0;                                                // the two WIDE projections (QKV, gate/up): x through LDS at every capacity
     float* d_part_row = nullptr;                                                // split-K partials of the SK_ROW projection
     int* d_row_cnt = nullptr;                                                   // its arrival counters (zero between launches)
     int attn_local = 1;                                                         // 1: workgroup-local join of the decode attention's splits where it applies (mk_dec_attn); 0 = always decode_attn_combine_kernel (A/B and test)
     int tome_fused_ln = 1;                                                      // 1: LayerNorm 2 of a merging ViT layer comes out of the ToMe merge launch (bitwise norm_kernel's result; 0 = its own launch, A/B and test only)
-    int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel; 2 (AUR_LABS builds): the same through round 3's inline-asm stores
+    int fused_reduce = 0;                                                       // 1: the split-K reduce runs inside the projection kernel
     hipGraphExec_t graph = nullptr, graph_h = nullptr;      // decode step: full grid / half grid (decode_half)
     int graph_batch = 0;
     // Generation banks: double-buffered per-batch state (KV slots, residual stream, sum(x^2), logits, outputs, graph) so
@@ -160,10 +160,7 @@ static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; 
 static hipError_t ctx_gemm(const aur_ctx* ctx, GemmArgs& a, int epi, hipStream_t s) {
     a.gemm_mode = ctx->gemm_mode;
     a.max_wgs = ctx->gemm_max_wgs;
-    a.wide_epilogue = ctx->gemm_wide;
-    a.tile_order = ctx->gemm_tile_order;
     a.tail_split = ctx->gemm_tail_split;
-    a.lab = ctx->gemm_lab;
     // Output policy.  A round of 256x256 tiles writes 256 x 128 KiB in one burst (every CU reaches its epilogue together) - the capacity
     // of the eight L2s; with the default policy that burst evicts the operand panels the next tiles share through L2.  Outputs the L2s
     // could not hold for the consumer anyway go out non-temporal (round 4: ViT fc1 +8 %, prefill gate/up +3 %, QKV +2-3 %); a single
@@ -1188,9 +1185,9 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     const int d = ctx->cfg.llm_hidden;
     SkinnyArgs o{};
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
-    o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn; o.waves = ctx->row_waves;
+    o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn;
     o.variant = ctx->skinny_variant; o.part = (d >= ctx->row_split_min_k || ctx->cfg.max_batch > 64) ? ctx->d_part_row : nullptr;
-    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; o.row_handover = ctx->fused_reduce;
+    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -1208,9 +1205,9 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     const int d = g.llm_hidden;
     SkinnyArgs dn{};
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
-    dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp; dn.waves = ctx->row_waves;
+    dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp;
     dn.variant = ctx->skinny_variant; dn.part = (g.llm_mlp >= ctx->row_split_min_k || g.max_batch > 64) ? ctx->d_part_row : nullptr;
-    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; dn.row_handover = ctx->fused_reduce;
+    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
     return dn;
 }
 
@@ -1452,10 +1449,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         ctx->tome_fused_ln = value ? 1 : 0;
         return AUR_OK;
     }
-    if (!strcmp(name, "dec_row_waves")) ctx->row_waves = (int)value;
-    else if (!strcmp(name, "dec_attn_local")) ctx->attn_local = value ? 1 : 0;
-    else if (!strcmp(name, "skinny_variant")) ctx->skinny_variant = ctx->skinny_variant_wide = value ? 1 : 0;
-    else if (!strcmp(name, "skinny_variant_wide")) ctx->skinny_variant_wide = value ? 1 : 0;
+    if (!strcmp(name, "dec_attn_local")) ctx->attn_local = value ? 1 : 0;
     else if (!strcmp(name, "skinny_row_split_min_k")) ctx->row_split_min_k = (int)value;
     else if (!strncmp(name, "gemm_", 5) || !strcmp(name, "microbench_prefill_nseq")) {
         // GEMM knobs: no GEMM is part of the captured decode step (its projections are the skinny kernels), so the graphs stay
@@ -1463,16 +1457,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
         if (!strcmp(name, "gemm_mode")) ctx->gemm_mode = (int)value;
         else if (!strcmp(name, "gemm_max_wgs")) ctx->gemm_max_wgs = (int)value;
         else if (!strcmp(name, "gemm_nt_out")) ctx->gemm_nt_out = value < 0 ? -1 : (value ? 1 : 0);
-        else if (!strcmp(name, "gemm_wide_epilogue")) ctx->gemm_wide = value ? 1 : 0;
-        else if (!strcmp(name, "gemm_tile_order")) ctx->gemm_tile_order = (value == 0 || value == 1) ? (int)value : 1;
         else if (!strcmp(name, "gemm_tail_split")) ctx->gemm_tail_split = value ? 1 : 0;
-        else if (!strcmp(name, "gemm_lab")) {
-#ifdef AUR_LABS
-            ctx->gemm_lab = (value >= 0 && value <= 26) ? (int)value : 0;       // lab kernels (gemm256.hip G2Lab): timing only, results are garbage
-#else
-            return aur_fail(ctx, AUR_ERR_ARG, "gemm_lab exists in AUR_LABS builds only (python -m aurora_amd.build --labs)");
-#endif
-        }
         else if (!strcmp(name, "microbench_prefill_nseq")) ctx->mb_nseq = (value >= 1 && value <= ctx->cfg.max_batch) ? (int)value : 1;
         else return aur_fail(ctx, AUR_ERR_ARG, "unknown option '%s'", name);
         return AUR_OK;
@@ -1484,12 +1469,7 @@ extern "C" int aur_set_option(aur_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "decode_fused_reduce")) {
         // 1: the split-K residual projections (o, down) sum their partials in the projection kernel (the last-arriving split reduces;
         // decode.hip "split-K with the reduce IN the kernel"); 0: a second launch does (skinny_row_reduce_kernel).  Bitwise the same tokens.
-        // 2 exists in AUR_LABS builds only: round 3's hazard-prone inline-asm partial stores, for tools/gpu/soak_fused_reduce.sh.
-#ifdef AUR_LABS
-        if (value < 0 || value > 2) return aur_fail(ctx, AUR_ERR_ARG, "decode_fused_reduce must be 0, 1 or 2 (lab)");
-#else
         if (value < 0 || value > 1) return aur_fail(ctx, AUR_ERR_ARG, "decode_fused_reduce must be 0 or 1");
-#endif
         ctx->fused_reduce = (int)value;
     } else if (!strcmp(name, "decode_stamp_layer")) {
         // value >= 0: two one-thread stamp launches bracket that layer's attention launch in every decode step (aur_decode_stamps_read);

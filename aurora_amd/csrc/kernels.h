@@ -31,16 +31,13 @@ struct GemmArgs {
     // ---- per-ctx tuning knobs (aur_set_option; filled by the engine at every launch - nothing is process-global)
     int gemm_mode;          // 0: 128x128 kernel only, 1: auto, 2: force 256x256 when Npad % 256 == 0
     int max_wgs;            // 256x256 kernel: > 0 = at most this many persistent workgroups (= CUs); 0 = one per CU
-    int wide_epilogue;      // 256x256 kernel: 1 = LDS-transposed full-line epilogue, 0 = direct 8-byte stores (bit-identical)
     int tail_split;         // 1 = a mostly idle last round of the 256x256 kernel is replaced by a 128x128 launch over the bottom rows
-    int tile_order;         // 256x256 kernel: 1 = rounds are compact blocks shared by the 8 XCDs (tile_order.h), 0 = per-XCD tile ranges
     int nt_out;             // 1 = the output of this launch is larger than the L2s together: written with non-temporal stores (ctx_gemm)
-    int lab;                // 0 in the product path; > 0 = lab instantiation of the 256x256 kernel (gemm256.hip G2Lab, EPI_ROW only)
     int tag;                // GT_*: which projection of the path this is.  No effect on the arithmetic: the 256x256 kernel is
                             // instantiated once per tag so that profiler traces (rocprofv3 groups by kernel NAME; the persistent
                             // grid is the same for every shape) separate the shapes - profiles/*_kernel_stats.txt, *_pmc.json
 };
-enum { GT_OTHER = 0, GT_VIT_QKV, GT_VIT_OUT, GT_VIT_FC1, GT_VIT_FC2, GT_LLM_QKV, GT_LLM_O, GT_LLM_GATEUP, GT_LLM_DOWN, GT_COUNT, GT_LAB_BASE = 32 };
+enum { GT_OTHER = 0, GT_VIT_QKV, GT_VIT_OUT, GT_VIT_FC1, GT_VIT_FC2, GT_LLM_QKV, GT_LLM_O, GT_LLM_GATEUP, GT_LLM_DOWN, GT_COUNT };
 
 hipError_t gemm_init();
 hipError_t attn_init();
@@ -135,7 +132,6 @@ struct SkinnyArgs {
     const half_t* W;        // FRAG-packed [Npad/16][K/32][512]
     int B, Npad, K, n_real;
     int mode;               // SK_ROW, SK_LOGITS, SK_SILU_MUL, SK_QKV
-    int waves;              // SK_ROW: 4 (default) or 8 waves per workgroup
     int b_lo, b_hi;         // only batch columns b_lo <= b < b_hi are stored
     half_t* xres;           // SK_ROW: residual stream in x-fragment form (K32 = n_real/32), updated in place: x += y
     unsigned long long* ssq_out;        // SK_ROW: sum(x_new^2) per row [AUR_SSQ_SLOTS][AUR_MAX_BATCH], 2^-28 fixed point, integer atomics
@@ -159,7 +155,6 @@ struct SkinnyArgs {
     int* row_cnt;           // variant 1, SK_ROW: arrival counters [Npad/16], zero between launches: the workgroup that completes a tile's 4
                             // partials sums them (fixed order) and runs the residual epilogue IN the projection kernel.  nullptr = a second
                             // launch does it (skinny_row_reduce_kernel; bitwise the same result)
-    int row_handover;       // AUR_LABS builds only: 2 = the partials go out through round 3's inline-asm stores (tools/gpu/soak_fused_reduce.sh)
     int gu_ks;              // variant 1, SK_SILU_MUL: k phases per tile, 2 (default) or 1 (engines of > 64 slots: the half grid needs it).
                             // A constant of the ENGINE: it fixes the summation order
     int half_grid;          // variant 1, > 64 rows, SK_QKV / SK_SILU_MUL: 1 = half as many workgroups with twice the tiles each, for

@@ -94,7 +94,6 @@ def parse():
                    help="with --pipeline: run the 256x256 GEMM persistently on at most this many workgroups (= CUs), leaving the "
                         "other CUs to the concurrently decoding stream; 0 = one workgroup per tile")
     p.add_argument("--gemm-tail-split", type=int, default=-1, help="A/B: 0 = one 256x256 launch per GEMM, 1 = idle last rounds go to the 128x128 kernel")
-    p.add_argument("--gemm-tile-order", type=int, default=-1, help="A/B: 0 = per-XCD tile ranges (old), 1 = compact blocks shared by the XCDs (default)")
     p.add_argument("--gemm-mode", type=int, default=-1, help="override the GEMM kernel choice (0: 128x128 only, 1: auto, 2: force 256x256)")
     p.add_argument("--prune-last", type=int, default=-1, help="A/B: 0 = the last prefill layer computes every row (as HF does), 1 (engine default) = K / V for every "
                    "row, the rest for each sequence's last 128 rows only (bitwise the same outputs)")
@@ -457,8 +456,6 @@ def main():
         eng.set_option("gemm_mode", args.gemm_mode)
     if args.gemm_cus > 0:
         eng.set_option("gemm_max_wgs", args.gemm_cus)
-    if args.gemm_tile_order >= 0:
-        eng.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.gemm_tail_split >= 0:
         eng.set_option("gemm_tail_split", args.gemm_tail_split)
     if args.prune_last >= 0:

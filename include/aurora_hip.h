@@ -236,26 +236,25 @@ int aur_vit_layer(aur_ctx* ctx, int32_t layer, const void* x, const float* size,
 /* Copy the last-position logits of the most recent prefill / decode step into dst_dev: fp32 [batch, vocab]. */
 int aur_copy_logits(aur_ctx* ctx, float* dst_dev, void* stream);
 
-/* Tuning knobs (invalidate the captured decode graph): "decode_fused_reduce" 0 (default: the split-K residual projections are followed by
- * a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same), "tome_fused_ln" 1 (default: LayerNorm 2 of a
- * merging ViT layer comes out of the ToMe merge launch) / 0 (its own launch; bitwise the same),
- * "dec_attn_local" 1 (default: on engines of 8-15 slots x 32 heads the splits of a (sequence, head) are the waves of one attention workgroup,
- * joined through LDS) / 0 (decode_attn_combine_kernel joins them; bitwise the same),
- * "dec_attn_pps" pages per
- * decode-attention split, "decode_stamp_layer" (see aur_decode_stamps_read), "dec_row_waves" 4/8, "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256),
- * "gemm_nt_out" -1 (default: GEMM outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always),
- * "gemm_max_wgs" n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile),
- * "gemm_wide_epilogue" 1 (LDS-transposed full-line stores) / 0 (direct), "skinny_variant" 0 (x fragments per wave) / 1 (x through
- * LDS; the default above 32 slots), "skinny_row_split_min_k", "gemm_tile_order" 1 (rounds of the persistent grid are
- * compact tile blocks shared by the XCDs) / 0 (per-XCD tile ranges), "gemm_tail_split" 1 (a mostly idle last round of the 256x256
- * kernel goes to the 128x128 kernel over the bottom rows) / 0, "microbench_prefill_nseq" sequences per pass for the pre_*
- * microbenchmarks.  "decode_half_grid" 1 / 0 does NOT invalidate the graphs (one is kept per setting): the next aur_llm_decode
- * calls go to a stream that owns half of the CUs, so the QKV / gate-up projections launch half as many workgroups with twice the
- * tiles each - bitwise the same tokens.  "prefill_prune_last" 1 (default) / 0: the last layer of a prefill computes K / V for every
- * position and the rest for each sequence's last 128 rows only - nothing else is read after it; bitwise the same logits and K / V; no graph
- * is affected.  The gemm_* knobs (incl. "gemm_lab": lab variants of AUR_LABS builds, timing only) keep the graphs as well: no GEMM
- * is part of the captured decode step.  Every knob is state of THIS ctx.  The gemm_* knobs and decode_half_grid are bit-neutral;
- * the dec_* / skinny_* knobs change how fp32 partial sums are partitioned (same tolerance, not bit-comparable across settings). */
+/* Tuning knobs.  Invalidate the captured decode graphs: "decode_fused_reduce" 0 (default: the split-K residual projections are followed
+ * by a reduce launch) / 1 (the last-arriving split reduces inside the kernel; bitwise the same), "dec_attn_local" 1 (default: on engines
+ * of 8-15 slots x 32 heads the splits of a (sequence, head) are the waves of one attention workgroup, joined through LDS) / 0
+ * (decode_attn_combine_kernel joins them; bitwise the same), "dec_attn_pps" pages per decode-attention split, "skinny_row_split_min_k"
+ * (K from which the residual projections of an engine of <= 64 slots take the split-K structure), "decode_stamp_layer" (see
+ * aur_decode_stamps_read).  Keep the graphs: "tome_fused_ln" 1 (default: LayerNorm 2 of a merging ViT layer comes out of the ToMe merge
+ * launch) / 0 (its own launch; bitwise the same); "prefill_prune_last" 1 (default) / 0: the last layer of a prefill computes K / V for
+ * every position and the rest for each sequence's last 128 rows only - nothing else is read after it; bitwise the same logits and K / V;
+ * "decode_half_grid" 1 / 0 (one graph is kept per setting): the next aur_llm_decode calls go to a stream that owns half of the CUs, so
+ * the QKV / gate-up projections launch half as many workgroups with twice the tiles each - bitwise the same tokens; the GEMM knobs (no
+ * GEMM is part of the captured decode step): "gemm_mode" 0 (128x128) / 1 (auto) / 2 (force 256x256), "gemm_nt_out" -1 (default: GEMM
+ * outputs larger than the eight L2s together, 32 MiB, are written with non-temporal stores) / 0 (never) / 1 (always), "gemm_max_wgs"
+ * n > 0: the 256x256 GEMM runs persistently on at most n workgroups (= CUs; 0 = one workgroup per tile), "gemm_tail_split" 1 (a mostly
+ * idle last round of the 256x256 kernel goes to the 128x128 kernel over the bottom rows) / 0, "microbench_prefill_nseq" sequences per
+ * pass for the pre_* microbenchmarks.  Every knob is state of THIS ctx.  The gemm_* knobs, tome_fused_ln, prefill_prune_last,
+ * dec_attn_local, decode_fused_reduce and decode_half_grid are bit-neutral; dec_attn_pps / skinny_row_split_min_k change how fp32
+ * partial sums are partitioned (same tolerance, not bit-comparable across settings).  Knobs whose losing arm was measured twice are
+ * gone (rounds 5-6): the decode structure is a function of the engine's capacity alone (x fragments per wave up to 32 slots, x through
+ * LDS above), the 256x256 GEMM always takes the LDS-transposed epilogue and the compact tile order, residual projections run 8 waves. */
 int aur_set_option(aur_ctx* ctx, const char* name, int64_t value);
 /* Time one kernel of the LLM path in isolation on the current generation state (after aur_llm_prefill):
  * kernel in {dec_norm, dec_qkv, dec_attn, dec_o, dec_gateup, dec_down, dec_lm_head, pre_norm, pre_qkv, pre_attn,

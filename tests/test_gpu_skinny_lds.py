@@ -18,8 +18,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def eng():
     from aurora_amd.engine import AuroraCapEngine
-    e = AuroraCapEngine({"vit": None, "llm": None}, {}, max_frames=1, max_batch=128)
-    e.set_option("skinny_variant", 1)
+    e = AuroraCapEngine({"vit": None, "llm": None}, {}, max_frames=1, max_batch=128)      # > 32 slots: x through LDS is this engine's structure
     yield e
     e.close()
 
@@ -38,8 +37,8 @@ def test_projection_through_lds_vs_fp32(eng, b, k, n):
 
 
 def lds_engine(cfg, seed, max_batch, use_graph=True):
-    e, w = make_engine(cfg, seed, max_batch=max_batch, use_graph=use_graph, max_ctx=256, max_new=16)
-    e.set_option("skinny_variant", 1)                 # the default above 32 slots; forced for the small-batch engines below
+    # the structure is a function of the engine's CAPACITY (> 32 slots), never of the live batch: small batches run on a 33-slot engine
+    e, w = make_engine(cfg, seed, max_batch=max(max_batch, 33), use_graph=use_graph, max_ctx=256, max_new=16)
     e.set_option("skinny_row_split_min_k", 128)       # tiny dims: send BOTH residual projections through the split-K + reduce path
     return e, w
 

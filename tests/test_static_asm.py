@@ -4,7 +4,7 @@ Round 3's fused split-K reduce wrote its partial tiles with inline asm (`global_
 different captions in one serving run of three.  Root cause (profiles/r04_fused_reduce_rootcause.txt): hipcc does not pad hazards
 inside an asm statement, and the compiled code rewrote the store's DATA registers one wait state after the store.  The rule these
 tests pin: in the product library every store of more than 64 bits is an instruction the COMPILER emitted (it pads and counts those);
-the only inline-asm stores live behind AUR_LABS."""
+no inline-asm store of more than 64 bits lives in the product sources."""
 import os
 import re
 import subprocess
@@ -57,13 +57,12 @@ def test_the_checker_flags_the_round3_form_and_accepts_the_padded_one():
     assert hazards(ok) == []
 
 
-def test_product_sources_hold_no_inline_asm_wide_store_outside_the_labs():
+def test_product_sources_hold_no_inline_asm_wide_store():
     pat = re.compile(r"asm\s+volatile\s*\(\s*\"[^;]*?_store_(dwordx3|dwordx4|b96|b128)")
     for f in sorted(os.listdir(CSRC)):
         src = open(os.path.join(CSRC, f)).read()
-        # drop the AUR_LABS regions
-        prod = re.sub(r"#ifdef AUR_LABS.*?#endif", "", src, flags=re.S)
-        assert not pat.search(prod), f"{f}: an inline-asm store of more than 64 bits in product code (use __builtin_amdgcn_raw_buffer_store_b128, or end the string with s_nop 1)"
+        assert "AUR_LABS" not in src, f"{f}: lab-only code in a product source (round 6 removed the lab build)"
+        assert not pat.search(src), f"{f}: an inline-asm store of more than 64 bits in product code (use __builtin_amdgcn_raw_buffer_store_b128, or end the string with s_nop 1)"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -4,7 +4,7 @@
 #   tools/gpu/lab.sh <task> [args] [-- <task> [args] ...]
 # tasks:
 #   tests [files...]        pytest -m gpu, one process per file (default: every tests/test_gpu_*.py)
-#   gemm                    tools/gemm_probe.py (shapes x both tile kernels, K sweep) + tools/gemm_lab/ts_probe.py (segment stamps, labs build)
+#   gemm                    tools/gemm_probe.py (shapes x both tile kernels, K sweep)
 #   micro <batch> [kernels] tools/microbench.py at <batch> slots
 #   bench <name> [flags]    python bench.py [flags] -> gpurun_out/bench_<name>.json (+ one line in bench.log)
 #   ab <flagA> <flagB> <pairs> [flags]   alternating bench pairs, e.g. ab "--fused-reduce 1" "--fused-reduce 0" 3 --steps 3
@@ -35,7 +35,6 @@ while [ $# -gt 0 ]; do
       grep -E "^===|passed|failed|error" gpurun_out/tests.log | tail -40 ;;
     gemm)
       timeout 900 python tools/gemm_probe.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/gemm.log
-      timeout 900 python tools/gemm_lab/ts_probe.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/gemm.log
       tail -80 gpurun_out/gemm.log ;;
     micro)
       b=${args[0]}; only=${args[1]:-}

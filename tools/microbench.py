@@ -72,24 +72,16 @@ def main():
             print(f"{tag:28s} {k:12s} {us:9.2f} us  {rate:9.1f} {unit}", flush=True)
 
     dec = ["dec_qkv", "dec_o", "dec_gateup", "dec_down", "dec_lm_head"]
-    for variant, tag in ((0, "decode x-per-wave"), (1, "decode x-through-LDS"))[(1 if B > 64 else 0):]:
-        eng.set_option("skinny_variant", variant)
-        run(tag, dec)
-    eng.set_option("skinny_variant", 1)
-    eng.set_option("skinny_variant", 1 if B > 32 else 0)
+    run("decode projections (the engine's structure for %d slots)" % B, dec)
     if not args.quick:
-        for nw in (4, 8):
-            eng.set_option("dec_row_waves", nw)
-            run(f"row kernels {nw} waves", ["dec_o", "dec_down"])
         run("attn (engine's splits)", ["dec_attn"])
         for pps in (1, 2, 4, 8, 19, 38):
             eng.set_option("dec_attn_pps", pps)
             run(f"attn pps{pps}", ["dec_attn"])
     else:
         run("attn (engine's splits)", ["dec_attn"])
-    for mode, wide, tag in ((0, 1, "prefill gemm128"), (2, 0, "prefill gemm256 direct stores"), (2, 1, "prefill gemm256 LDS epilogue")):
+    for mode, tag in ((0, "prefill gemm128"), (2, "prefill gemm256")):
         eng.set_option("gemm_mode", mode)
-        eng.set_option("gemm_wide_epilogue", wide)
         run(tag, ["pre_qkv", "pre_o", "pre_gateup", "pre_down"])
     eng.set_option("gemm_mode", 1)
     if args.ab_option:
