@@ -129,9 +129,9 @@ def parse():
                    help="overlapped schedule: 1 (default) = a group's front end (ViT + ToMe + projector / splice + staged prefill) is ONE captured hipGraph "
                         "(engine.FrontEndGraph: inputs copied into static buffers, one replay per group); 0 = ~500 eager launches per group.  Same ids")
     p.add_argument("--ttft-gate-steps", type=int, default=0,
-                   help="overlapped schedule: bounded run-ahead - the host submits a group's front end only when the device is within this many decode steps of "
-                        "the end of the PREVIOUS chunk (the commit that precedes the front end's start), so that the host-observed submit -> first-token "
-                        "time stays close to the device interval; -1 = unbounded (rounds 2-5: the enqueue thread ran > 1 s ahead)")
+                   help="overlapped schedule: bounded run-ahead - the host submits a group's front end only when the device is within this many + 1 decode "
+                        "steps of the point where that front end may start, so that the host-observed submit -> first-token time stays close to the "
+                        "device interval; -1 = unbounded (rounds 2-5: the enqueue thread ran > 1 s ahead)")
     p.add_argument("--no-stamps", action="store_true", help="do not stamp the decode attention of one layer inside the captured step (roofline.frac_in_timed_loop)")
     p.add_argument("--ttft-delay-steps", type=int, default=-1, help="overlapped schedule: the front end of a group starts this many decode steps after the previous "
                    "boundary instead of at it (-1 = calibrated in the warm-up cycle so that it finishes just before its own boundary: no commit wait)")
@@ -757,38 +757,72 @@ def main():
                             e2 = torch.cuda.Event()
                             e2.record(sC)
                         host_q.put((t_host[0], t_host[1], e2))
-                    # the chunk's decode is enqueued BEFORE the next front end (a few hundred launches on the host): both wait for
-                    # the commit only, and the decode must never sit behind the host's enqueue time
-                    n = (offs[g + 1] if g + 1 < NG else S) - offs[g]
-                    k1 = min(n, k_masked) if sDm is not None else 0
-                    # latency-priority order of a chunk (round 5): the steps that run WITHOUT a front end beside them come first, the next
-                    # group's front end starts after them and ends at its own boundary - it used to start at the previous boundary and then
-                    # wait out those steps (`commit_wait`, 34-39 ms of every TTFT).  Same steps, same kernels, same ids.
-                    lead = (n - k1 if args.ttft_delay_steps < 0 else min(args.ttft_delay_steps, n - k1)) if k1 > 0 else 0
-                    go = e1
+                    # One chunk of decode steps: `lead` steps on the whole chip, then - `go` - the next group's front end may start on the front-end
+                    # stream while `k1` steps run on the complementary CU mask, then the rest unmasked.  Latency-priority order (round 5): the
+                    # steps WITHOUT a front end beside them come first, so the front end ends at its own boundary (no commit wait).
+                    def chunk_plan(gi):
+                        n_ = (offs[gi + 1] if gi + 1 < NG else S) - offs[gi]
+                        k_ = min(n_, k_masked) if sDm is not None else 0
+                        l_ = (n_ - k_ if args.ttft_delay_steps < 0 else min(args.ttft_delay_steps, n_ - k_)) if k_ > 0 else 0
+                        return n_, k_, l_
+
+                    n, k1, lead = chunk_plan(g)
                     rest = n - k1 - lead
-                    # bounded run-ahead (TTFT runs from the SUBMISSION of a request): the chunk's LAST segment records `gate`
-                    # --ttft-gate-steps decode steps before its end; the next iteration submits its front end only once the device is there
-                    gate_at = max(0, args.ttft_gate_steps)
-                    last_seg = "rest" if rest > 0 else ("masked" if k1 > 0 else "lead")
-                    gate_next = [None]
+                    # bounded run-ahead (TTFT runs from the SUBMISSION of a request).  The front end of group g + 1 may start after
+                    # `lead` steps of this chunk; the host submits it when the device is `margin` = --ttft-gate-steps + 1 steps before that
+                    # point - an event recorded inside this chunk's lead segment, or (lead < margin) inside the PREVIOUS chunk's tail - and
+                    # never earlier.  The decode replays themselves are enqueued at most three blocks of 8 steps ahead of the device (the
+                    # enqueue thread sleeps instead of spinning in the runtime's back-pressure: cfg5's chunks are 170 steps long).
+                    margin = max(0, args.ttft_gate_steps) + 1
+                    marks = {}                                             # steps of this chunk enqueued -> record an event on the current stream
+                    gate_in = [None]
+                    if gate_on and lead - margin >= 0:
+                        marks[lead - margin] = lambda: gate_in.__setitem__(0, _record())
+                    tail = [None]
+                    if gate_on:
+                        _, _, lead_nx = chunk_plan((g + 1) % NG)
+                        if lead_nx - margin < 0:                            # the next iteration's gate lies in this chunk's tail
+                            marks[max(n - (margin - lead_nx), 0)] = lambda: tail.__setitem__(0, _record())
 
-                    def decode_seg(steps, seg):
-                        if gate_on and seg == last_seg:
-                            pre = max(steps - gate_at, 0)
-                            if pre > 0:
-                                eng.decode(pre)
-                            gate_next[0] = torch.cuda.Event()
-                            gate_next[0].record(torch.cuda.current_stream())
-                            if steps - pre > 0:
-                                eng.decode(steps - pre)
-                        else:
-                            eng.decode(steps)
+                    def _record():
+                        ev_ = torch.cuda.Event()
+                        ev_.record(torch.cuda.current_stream())
+                        return ev_
 
+                    def decode_seg(steps, base):
+                        i_ = 0
+                        while True:
+                            if base + i_ in marks:
+                                marks.pop(base + i_)()
+                            if i_ >= steps:
+                                break
+                            stops = [m - base for m in marks if base + i_ < m <= base + steps] + [steps] + ([i_ + 8] if gate_on else [])
+                            nxt_ = min(stops)
+                            eng.decode(nxt_ - i_)
+                            i_ = nxt_
+                            if gate_on:                                     # pacing: at most three blocks of replays queued ahead of the device
+                                pace_q.append(_record())
+                                if len(pace_q) > 3:
+                                    sleep_wait(pace_q.pop(0))
+
+                    go = e1
                     if lead > 0:
-                        decode_seg(lead, "lead")
+                        decode_seg(lead, 0)
                         go = torch.cuda.Event()
                         go.record(sD)
+                    elif 0 in marks:
+                        marks.pop(0)()                                      # lead == 0: a mark at the chunk's start sits right behind the commit
+                    sF.wait_event(go)
+                    gate = gate_in[0] if gate_in[0] is not None else gate_prev[0]
+                    if gate_on and gate is not None:
+                        t_w = time.perf_counter()
+                        sleep_wait(gate)                                    # the device is `margin` steps from the point where this front end may start
+                        if timed:
+                            host_enq["gate_wait_s"] = host_enq.get("gate_wait_s", 0.0) + time.perf_counter() - t_w
+                    # the front end is ONE graph replay now: it is submitted before the rest of the chunk's replays (eagerly enqueued - a few
+                    # hundred launches on the host - it goes last: the decode must never sit behind the host's enqueue time)
+                    if fe["use"]:
+                        pending[0] = front_async((g + 1) % NG)
                     if k1 > 0:
                         sDm.wait_event(go)
                         with torch.cuda.stream(sDm):
@@ -797,7 +831,7 @@ def main():
                                 evm0.record(sDm)
                             eng.set_option("decode_half_grid", half_grid)   # half as many workgroups, twice the tiles each
                             try:
-                                decode_seg(k1, "masked")
+                                decode_seg(k1, lead)
                             finally:                                        # a failed decode must not leave the ctx on the half grid
                                 eng.set_option("decode_half_grid", 0)
                             evm = torch.cuda.Event(enable_timing=k_cal["on"])
@@ -806,15 +840,10 @@ def main():
                                 k_cal["dec_ev"].append((evm0, evm, k1))
                         sD.wait_event(evm)
                     if rest > 0:
-                        decode_seg(rest, "rest")
-                    sF.wait_event(go)
-                    if gate_on and gate_prev[0] is not None:
-                        t_w = time.perf_counter()
-                        sleep_wait(gate_prev[0])                            # the device is within `gate_at` steps of this group's commit
-                        if timed:
-                            host_enq["gate_wait_s"] = host_enq.get("gate_wait_s", 0.0) + time.perf_counter() - t_w
-                    gate_prev[0] = gate_next[0]
-                    pending[0] = front_async((g + 1) % NG)
+                        decode_seg(rest, lead + k1)
+                    gate_prev[0] = tail[0]
+                    if not fe["use"]:
+                        pending[0] = front_async((g + 1) % NG)
                     if args.sync_chunks:
                         sD.synchronize()
                 if timed:
@@ -834,6 +863,7 @@ def main():
             sF.wait_stream(sD)
             gate_on = args.ttft_gate_steps >= 0
             gate_prev = [None]
+            pace_q = []
             if args.front_graph:
                 from aurora_amd.engine import FrontEndGraph
                 t_cap = time.perf_counter()
@@ -1053,8 +1083,8 @@ def main():
             # memory; the device-event interval (what rounds 1-5 reported under this name) stays beside it
             "p50_ttft_ms": (float(np.median(submit_ttft)) if (continuous and overlap and gate_on and submit_ttft) else (float(np.median(ttft_ms)) if ttft_ms else None)),
             "p50_ttft_definition": ("host clock: submission of a group's front end (host call) -> its first token ids in pinned host memory; the host submits a "
-                                    "front end only when the device is within %d decode step(s) of the commit that precedes its start (bounded run-ahead)"
-                                    % max(args.ttft_gate_steps, 0)) if (continuous and overlap and gate_on and submit_ttft) else "device-event interval (see ttft_note)",
+                                    "front end only when the device is within %d decode step(s) of the point where that front end may start (bounded run-ahead)"
+                                    % (max(args.ttft_gate_steps, 0) + 1)) if (continuous and overlap and gate_on and submit_ttft) else "device-event interval (see ttft_note)",
             "p50_ttft_device_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "p90_ttft_ms": (float(np.percentile(submit_ttft, 90)) if (continuous and overlap and gate_on and submit_ttft) else None),
             "power": power, "power_sampling": ("off" if not (rank == 0 and want_power) else (power or {}).get("how", "no samples")),
