@@ -350,7 +350,7 @@ def thread_cpu_seconds():
                 st = open(f"/proc/self/task/{tid}/stat").read()
                 name = st[st.index("(") + 1:st.rindex(")")]
                 f = st[st.rindex(")") + 2:].split()
-                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+                out[int(tid)] = (name + (" (main)" if int(tid) == os.getpid() else ""), (int(f[11]) + int(f[12])) / tick)
             except (OSError, ValueError):
                 pass
     except OSError:
@@ -1118,6 +1118,8 @@ def main():
             "process_cpu_s_per_cycle": (host_enq["cpu_s"] / args.steps) if "cpu_s" in host_enq else None,
             "process_cpu_util": (host_enq["cpu_s"] / elapsed) if "cpu_s" in host_enq else None,
             "busiest_threads_cpu_s_per_cycle": host_enq.get("threads"),
+            "busiest_threads_note": "user + system seconds per cycle of the process's threads over the timed steps (/proc/self/task); the thread that is busy for the "
+                                    "whole cycle is not Python's: the enqueue thread is the one marked (main), the two TTFT helpers and the power sampler follow",
             "gate_wait_s_per_cycle": (host_enq.get("gate_wait_s", 0.0) / host_enq["cycles"]) if host_enq["cycles"] else None,
             "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe["graph"].nodes, "replays_per_cycle": NG,
                            "capture_s": fe.get("capture_s"), "decode_graph_replays_per_cycle": S,
@@ -1176,7 +1178,7 @@ def main():
         pmc, pmc_ctx, pmc_tag, pmc_build, pmc_all = {}, None, "r02", None, []
         try:
             pj = None
-            for tag in ("r05", "r04", "r03", "r02"):                   # the newest committed counter summary
+            for tag in ("r06", "r05", "r04", "r03", "r02"):                   # the newest committed counter summary
                 fp = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
                 if os.path.exists(fp):
                     pj, pmc_tag = json.load(open(fp)), tag
@@ -1314,6 +1316,14 @@ def main():
         torch.cuda.synchronize()
         st1 = {k: eng.profile_read(k)[0] for k in ("vit", "vit_tome", "project", "prefill", "first_token")}
         eng.profile(False)
+        # the ToMe launches at the frames per launch of the TIMED loop (one group of G clips per ViT pass), alone on the whole chip
+        tome_group_ms = None
+        if continuous and G * F <= eng.c.max_frames:
+            eng.profile(True)
+            eng.vit_encode(pixels[:G * F], r)
+            torch.cuda.synchronize()
+            tome_group_ms = eng.profile_read("vit_tome")[0]
+            eng.profile(False)
         # ---- token merge against its HBM bound (north_star: "evidenced by rocprof HBM GB/s"; SURVEY 8d bytes per frame-layer =
         #      2 (t c + t D + (t - r) D) + 4 (2 t - r): the metric, the state read and the merged state written, the index arrays)
         if not args.tiny:
@@ -1348,6 +1358,10 @@ def main():
                 "ms_per_clip": (tome_ms_batch / B) if tome_ms_batch > 0 else None, "frames_per_launch": sv_clips * F,
                 "single_clip": {"ms": st1["vit_tome"], "achieved": tome_bytes_clip / (st1["vit_tome"] * 1e-3) / 1e9 if st1["vit_tome"] > 0 else None,
                                 "frac": tome_bytes_clip / (st1["vit_tome"] * 1e-3) / 8e12 if st1["vit_tome"] > 0 else None, "frames_per_launch": F},
+                "timed_loop_group": ({"ms": tome_group_ms, "clips": G, "frames_per_launch": G * F, "achieved": G * tome_bytes_clip / (tome_group_ms * 1e-3) / 1e9,
+                                     "frac": G * tome_bytes_clip / (tome_group_ms * 1e-3) / 8e12,
+                                     "note": "the launch shape of the timed loop (one group of %d clips per ViT pass), measured alone on the whole chip; in the loop it "
+                                             "runs on 16 CUs of every XCD beside the decode" % G} if tome_group_ms else None),
                 "how": "HIP events around the ToMe launches of every layer (aur_profile 'vit_tome') in the instrumented eager step (%d clips per ViT pass) and in "
                        "one single-clip pass; the merge launch also writes LayerNorm 2's output (not counted in the algorithmic bytes)" % sv_clips}
         result["ttft_stage_ms"] = {

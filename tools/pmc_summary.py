@@ -81,8 +81,12 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     batch_x_ctx = float(sys.argv[3]) if len(sys.argv) > 3 else 64 * 2145.0     # decode attention: sequences x mean cached tokens of the pass
     F, W, M = (read_pass(os.path.join(root, p)) for p in ("pmc_fetch", "pmc_write", "pmc_mfma"))
+    # optional fourth pass (round 6): TCC_EA0_RDREQ_LEVEL_sum / TCC_EA0_RDREQ_sum = mean L2-to-fabric read latency in L2 clocks - the only
+    # handle this rocprofv3 gives on WHERE a kernel's fabric reads are served (no DRAM-side counter: profiles/r06_rocprof_ea_counters.txt):
+    # a stream from HBM (the decode attention) is the yardstick, reads served by the memory-side cache come back sooner
+    E = read_pass(os.path.join(root, "pmc_ealat")) if os.path.isdir(os.path.join(root, "pmc_ealat")) else {}
     ours = lambda k: k and not (k.startswith("void at::") or "rocprim" in k or k.startswith("__amd_rocclr") or "hipcub" in k)
-    keys = sorted({k for k in list(F) + list(W) + list(M) if ours(k[0])})
+    keys = sorted({k for k in list(F) + list(W) + list(M) + list(E) if ours(k[0])})
     res = {"_note": "per (kernel, grid): means over the dispatches of `bench.py --batch B --prefill-group 4 --batch-mode --steps 1 --warmup 0 --max_new_tokens 6 --no-graph` "
                     "(B x 2145 = _batch_x_ctx: the decode attention's sequences x cached tokens in this pass) under three "
                     "separate rocprofv3 --pmc passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH half-count correction); "
@@ -91,6 +95,8 @@ def main():
     mean = lambda a, c: (a[c][0] / a[c][1]) if c in a and a[c][1] else None
     for k in keys:
         f, w, m = F.get(k, {}), W.get(k, {}), M.get(k, {})
+        ea = E.get(k, {})
+        lvl, req = mean(ea, "TCC_EA0_RDREQ_LEVEL_sum"), mean(ea, "TCC_EA0_RDREQ_sum")
         e = {"kernel": k[0], "grid": k[1], "dispatches": int(max([v[1] for a in (f, w, m) for c, v in a.items() if not c.startswith("_")] or [0]))}
         fk, wk = mean(f, "FETCH_SIZE"), mean(w, "WRITE_SIZE")
         if fk is not None:
@@ -107,13 +113,16 @@ def main():
             if d:
                 e["avg_us_under_pmc"] = d / 1e3
                 e["clock_ghz"] = gui / XCDS / d
+        if lvl is not None and req:
+            e["ea_read_latency_clk"] = lvl / req
+            e["ea_read_requests"] = req
         res["kernels"].append(e)
     res["kernels"].sort(key=lambda e: -(e.get("avg_us_under_pmc", 0) * e["dispatches"]))
     json.dump(res, open(out, "w"), indent=1)
-    print(f"{'kernel':70s} {'grid':>10s} {'n':>6s} {'us':>9s} {'HBM MB':>9s} {'mfma%':>6s} {'GHz':>5s}")
+    print(f"{'kernel':70s} {'grid':>10s} {'n':>6s} {'us':>9s} {'HBM MB':>9s} {'mfma%':>6s} {'GHz':>5s} {'EA rd lat':>9s}")
     for e in res["kernels"][:40]:
         print(f"{e['kernel'][:70]:70s} {e['grid']:>10s} {e['dispatches']:6d} {e.get('avg_us_under_pmc', 0):9.1f} "
-              f"{e.get('hbm_bytes_per_launch', 0) / 1e6:9.1f} {100 * e.get('mfma_util', 0):6.1f} {e.get('clock_ghz', 0):5.2f}")
+              f"{e.get('hbm_bytes_per_launch', 0) / 1e6:9.1f} {100 * e.get('mfma_util', 0):6.1f} {e.get('clock_ghz', 0):5.2f} {e.get('ea_read_latency_clk', 0):9.0f}")
 
 
 if __name__ == "__main__":

@@ -19,12 +19,12 @@ for attempt in 1 2 3; do      # the tracer itself segfaults now and then inside 
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_shapes.txt" > /dev/null
-# 1b. (round 5) the kernels of the schedule the driver TIMES: the default overlapped continuous-batching loop itself,
-#     with the decode stream synchronised once per chunk (--sync-chunks: <= 8 graph replays queued, which the tracer survives; the
-#     synchronisation is off in timed runs and costs the traced run a few per cent).  One fill + one warm-up + one timed cycle.
+# 1b. (round 5) the kernels of the schedule the driver TIMES: the default overlapped continuous-batching loop itself.
+#     Round 6: the loop bounds its own run-ahead (<= 24 graph replays queued, front ends as graph replays), which the tracer survives as
+#     it is - no --sync-chunks any more: this IS the timed loop.  One fill + warm-up cycles + one timed cycle.
 for attempt in 1 2 3; do
   rm -rf "$OUT/trace_ov"
-  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ov" -o trace -- $BENCH --steps 1 --warmup 1 --sync-chunks --no-instrument --no-single-stream > "$OUT/trace_ov.log" 2>&1 && break
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ov" -o trace -- $BENCH --steps 1 --warmup 2 --no-instrument --no-single-stream --no-latency-point > "$OUT/trace_ov.log" 2>&1 && break
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace_ov" "$OUT/${TAG}_kernel_stats_overlapped.txt" > /dev/null
 python "$REPO/tools/overlap_trace_summary.py" "$OUT/trace_ov" > "$OUT/${TAG}_overlap_trace_summary.txt" 2>&1
@@ -48,6 +48,7 @@ pmc_pass() {   # name, counters...
 pmc_pass fetch FETCH_SIZE
 pmc_pass write WRITE_SIZE
 pmc_pass mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+pmc_pass ealat TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum
 python "$REPO/tools/pmc_summary.py" "$OUT" "$OUT/${TAG}_pmc.json" $(( ${PMC_BATCH:-128} * 2145 )) > "$OUT/${TAG}_pmc_summary.txt" 2>&1
 # keep the merge-back under 64 MiB: drop the raw per-dispatch csv / db files, keep logs + summaries
 for f in $(find "$OUT" -name "*counter_collection.csv" | head -3); do head -3 "$f" > "$f.head.txt"; done
