@@ -29,8 +29,6 @@
 //   one query per (sequence, head): see decode_attn_dot_kernel.
 #include "kernels.h"
 
-#include <type_traits>
-
 // address (halves) of the 16-byte piece holding x[b][k .. k+8) (k % 8 == 0) in x-fragment form
 __device__ __forceinline__ int64_t xfrag_piece(int b, int k, int K32) {
     return ((((int64_t)(b >> 4) * K32 + (k >> 5)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8;
@@ -1035,31 +1033,27 @@ __global__ __launch_bounds__(64 * S, S == 1 ? 2 : 1) void decode_attn_dot_kernel
     const int64_t koff = kfrag_off(kv, head, 0, 0) + lane * 8;
     const int64_t voff = vfrag_off(kv, head, 0, 0) + lane * 8;
 
-    // ---- the page pipeline.  One step = one 64-token page: request the page's V^T fragments (the products of the previous step have just
-    // read those registers), scores from the K fragments in `kf` (requested one step earlier), request the NEXT page's K fragments into `kf`,
-    // softmax over the page, output update.  The last page is a PEELED step without the K request (MORE is a compile-time flag), so every
-    // s_waitcnt is an exact count.  Round 5's loop issued K(p + 1) under a run-time `if (more)`; hipcc then sized the waits of the V products
-    // for the path WITHOUT those requests - vmcnt(15 .. 0) instead of vmcnt(31 .. 16) - and every step drained K(p + 1) before its last V
-    // product: the prefetch never outlived the step that issued it (guide 5, trap (c): a load under a run-time condition makes hipcc wait
-    // vmcnt(0)).  Peeled: 709 -> 654 us at 128 x 32 x 2143 on the whole chip (6.87 TB/s), unchanged on 16 CUs per XCD (753 us = 5.97 TB/s: there the
-    // ~47 GB/s a CU can keep in flight binds - a plain streaming kernel reaches the same 5.5-5.8 TB/s on those CUs, profiles/r03_mall_lab.log).
-    // Also measured (tools/gpu/attn_ab.py, profiles/r06_attn_pipeline_ab.log): V^T of page p + 1 requested a whole step ahead into a second
-    // register set (316 registers: one wave per SIMD) - 654 / 743 us: nothing, removed.  Same operations on the same values in the same
-    // order as before: same bits.
-    h8 kf[4 * KBLK], va[VD16 * 2];
-    auto load_k = [&](int p) {
-        const half_t* pg = kv_page(kv, seq, p * 64);
+    // ---- the page pipeline: K of page p + 1 is requested into the registers the Q K^T products of page p have just read, V^T of page p at the
+    // top of its step.  hipcc sizes the waits of the V products for the path on which the conditional K requests were NOT issued
+    // (`s_waitcnt vmcnt(15 .. 0)` where `vmcnt(31 .. 16)` would do), i.e. every step drains K(p + 1) before its last V product.  Round 6 built
+    // the exact-count forms - the last page as a peeled step, and on top of it V^T requested a whole step ahead into a second register set
+    // (316 registers, one wave per SIMD) - and measured them against this loop in one process (tools/gpu/attn_ab.py at 128 x 32 x 2143,
+    // profiles/r06_attn_pipeline_ab.log, r06_attn_pipeline_ab2.log): whole chip 656 -> 652 / 654 us, 16 CUs per XCD (the masked steps of the
+    // serving loop: seven of eight) 750 -> 753 / 743 us.  Nothing: the kernel is bound by what a CU keeps in flight (~47 GB/s per CU on half of
+    // the chip, 19.6 B per clock - a plain streaming kernel reaches the same 5.5-5.8 TB/s there, profiles/r03_mall_lab.log) and by HBM on
+    // the whole chip (6.85 TB/s), not by its own waits.  The loop stays as it was.
+    h8 kf[4 * KBLK];
+    if (p_first < p_last) {
+        const half_t* page = kv_page(kv, seq, p_first * 64);
 #pragma unroll
-        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(pg + koff + i * AUR_FRAG_HALVES));
-    };
-    auto load_v = [&](h8 (&vf)[VD16 * 2], int p) {
-        const half_t* pg = kv_page(kv, seq, p * 64);
+        for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(page + koff + i * AUR_FRAG_HALVES));
+    }
+    for (int p = p_first; p < p_last; ++p) {
+        const half_t* page = kv_page(kv, seq, p * 64);
+        h8 vf[VD16 * 2];
 #pragma unroll
-        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(pg + voff + i * AUR_FRAG_HALVES));
-    };
-    // scores + softmax statistics of page p -> p16 (this page's probabilities, one per lane) and alpha; the K requests of page p + 1 go out
-    // as soon as the products have read the registers
-    auto scores = [&](int p, auto more) -> float {
+        for (int i = 0; i < VD16 * 2; ++i) vf[i] = __builtin_nontemporal_load((const h8*)(page + voff + i * AUR_FRAG_HALVES));
+        const bool more = p + 1 < p_last;                 // wave-uniform
         const int key0 = p * 64;
         float s[4];
 #pragma unroll
@@ -1069,7 +1063,11 @@ __global__ __launch_bounds__(64 * S, S == 1 ? 2 : 1) void decode_attn_dot_kernel
             for (int blk = 0; blk < KBLK; ++blk) part = dot8(kf[kt * KBLK + blk], qf[blk], part);
             s[kt] = part;
         }
-        if constexpr (decltype(more)::value) load_k(p + 1);
+        if (more) {                                       // K of the next page into the registers the products above have just read
+            const half_t* pn = kv_page(kv, seq, (p + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 4 * KBLK; ++i) kf[i] = __builtin_nontemporal_load((const h8*)(pn + koff + i * AUR_FRAG_HALVES));
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -1093,9 +1091,6 @@ __global__ __launch_bounds__(64 * S, S == 1 ? 2 : 1) void decode_attn_dot_kernel
         }
         l_run = l_run * alpha + ps;
         p16[lane] = (half_t)mine;
-        return alpha;
-    };
-    auto update = [&](const h8 (&vf)[VD16 * 2], float alpha) {
         h8 pf[2];
 #pragma unroll
         for (int b32 = 0; b32 < 2; ++b32) {               // PAIRED token order of a V^T fragment: tokens 4g .. 4g + 3 and 16 + 4g .. of the 32
@@ -1110,18 +1105,6 @@ __global__ __launch_bounds__(64 * S, S == 1 ? 2 : 1) void decode_attn_dot_kernel
             o = dot8(vf[d * 2 + 1], pf[1], o);
             acc_o[d] = o;
         }
-    };
-    using T1 = std::integral_constant<bool, true>;
-    using T0 = std::integral_constant<bool, false>;
-    if (p_first < p_last) {
-        load_k(p_first);
-        int p = p_first;
-        for (; p + 1 < p_last; ++p) {
-            load_v(va, p);
-            update(va, scores(p, T1{}));
-        }
-        load_v(va, p);
-        update(va, scores(p, T0{}));
     }
     float l = l_run;
 #pragma unroll

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(1024) void tome_prep_kernel(KvLayout kv, const floa
                 const half_t* p0 = page + kfrag_off(kv, 0, tok >> 4, blk) + fl * 8;
                 const int64_t hstride = kfrag_off(kv, 1, 0, 0) - kfrag_off(kv, 0, 0, 0);
                 int h = 0;
-                // sixteen, then four independent 16-byte loads in flight per thread; summed in head order whatever the batching (round 6: with
-                // four in flight the launch ran at 1.4 TB/s - 72 MB of K fragments in 50 us at 32 frames - a latency-bound read)
+                // sixteen, then four independent 16-byte loads in flight per thread; summed in head order whatever the batching (round 6; four
+                // in flight before: 37.4 -> 36.8 us at 128 frames per launch in the kernel trace - the launch is not short of loads in flight)
                 for (; h + 16 <= kv.heads; h += 16) {
                     h8 v[16];
 #pragma unroll

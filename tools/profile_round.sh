@@ -22,9 +22,11 @@ python "$REPO/tools/rocprof_summary.py" shapes "$OUT/trace" "$OUT/${TAG}_kernel_
 # 1b. (round 5) the kernels of the schedule the driver TIMES: the default overlapped continuous-batching loop itself.
 #     Round 6: the loop bounds its own run-ahead (<= 24 graph replays queued, front ends as graph replays), which the tracer survives as
 #     it is - no --sync-chunks any more: this IS the timed loop.  One fill + warm-up cycles + one timed cycle.
-for attempt in 1 2 3; do
+# the tracer (rocprofv3 of this image) segfaults in some runs of the loop as it is; fall back to a chunk-synchronised loop, then to eager front ends
+for extra in "" "--sync-chunks" "--sync-chunks --front-graph 0"; do
   rm -rf "$OUT/trace_ov"
-  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ov" -o trace -- $BENCH --steps 1 --warmup 2 --no-instrument --no-single-stream --no-latency-point > "$OUT/trace_ov.log" 2>&1 && break
+  echo "overlapped trace: flags [$extra]" >> "$OUT/trace_ov_attempts.log"
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ov" -o trace -- $BENCH --steps 1 --warmup 2 --no-instrument --no-single-stream --no-latency-point $extra > "$OUT/trace_ov.log" 2>&1 && break
 done
 python "$REPO/tools/rocprof_summary.py" stats "$OUT/trace_ov" "$OUT/${TAG}_kernel_stats_overlapped.txt" > /dev/null
 python "$REPO/tools/overlap_trace_summary.py" "$OUT/trace_ov" > "$OUT/${TAG}_overlap_trace_summary.txt" 2>&1
