@@ -1279,6 +1279,14 @@ def main():
                                                    "mfma_util_pmc": g_ent.get("mfma_util") if g_ent else None,
                                                    "clock_ghz_pmc": g_ent.get("clock_ghz") if g_ent else None,
                                                    "traffic": g_ent.get("hbm_bytes_per_launch") if g_ent else None,
+                                                   "traffic_is": "L2-to-fabric bytes (FETCH_SIZE / WRITE_SIZE count the TCC_EA0 interface: reads served by the memory-side "
+                                                                 "cache are included; this rocprofv3 has no DRAM-side counter, profiles/r06_rocprof_ea_counters.txt)",
+                                                   "fabric_read_latency_l2_clk": ({"this_gemm": g_ent.get("ea_read_latency_clk"),
+                                                                                   "decode_attention_streaming_from_hbm": (pmc_of("decode_attn_dot_kernel") or {}).get("ea_read_latency_clk"),
+                                                                                   "how": "TCC_EA0_RDREQ_LEVEL_sum / TCC_EA0_RDREQ_sum of the counter pass: mean latency of an L2-to-fabric read; a "
+                                                                                          "stream from HBM is the yardstick - the GEMM's operand re-reads come back several times sooner, i.e. mostly "
+                                                                                          "from the memory-side cache, in a pass where nothing else streams through it"}
+                                                                                  if g_ent and g_ent.get("ea_read_latency_clk") else None),
                                                    "how": "aur_microbench: 32 back-to-back launches per projection cycling through the layers (HIP events)"}
             except Exception as ex:                                # the bench line must still print
                 result["roofline_prefill_gemm"] = {"error": repr(ex)}
