@@ -12,7 +12,12 @@
 // traffic besides the lane-linear K/V fragment reads (ds_read_b128 at base + lane*16, conflict-free).
 // K/V tiles are staged by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per 64 keys.
 // A workgroup = 4 waves x 32 queries; each wave keeps 2 query tiles so every K/V fragment read feeds
-// two MFMAs.
+// two MFMAs.  (Round 6 built the 4-tile form - 64 queries per wave, half the LDS reads per flop, 321 registers = one wave per SIMD at
+// head_dim 128, 235 = two at head_dim 80 - as a template parameter and measured it against this one in one process, bitwise the same output
+// (profiles/r06_attn_qtiles_ab.log): Llama prefill attention 4 x 2142 245 -> 352 us, 1 x 2142 82 -> 103 us, a ViT pass of 32 frames
+// 26.03 -> 26.2 ms.  As hipcc schedules it, one wave per SIMD runs its QK MFMAs, its softmax and its PV MFMAs one after the other; with
+// 2-3 waves per SIMD they overlap across waves.  The 4-tile form needs the hand-placed MFMA / VALU interleave of the guide's T15 / T19;
+// not kept.)
 #include "kernels.h"
 
 template <int KBLK, int VD16>
