@@ -1178,7 +1178,7 @@ static DecAttnArgs mk_dec_attn(aur_ctx* ctx, int l) {
     at.part_o = ctx->d_part_o; at.part_ml = ctx->d_part_ml; at.out_f = ctx->d_attn; at.out_k32 = g.llm_hidden / 32;
     // engines whose capacity alone gives one attention workgroup per CU and still split the context (8-15 slots of 32 heads): the splits of a
     // (sequence, head) are the waves of one workgroup and meet in LDS - bitwise the two-launch result, one launch per layer less
-    at.local_splits = (g.max_batch * g.llm_heads >= 256 && (ctx->nsplit == 2 || ctx->nsplit == 4) && ctx->l_hd == 128 && ctx->attn_local) ? ctx->nsplit : 0;
+    at.local_splits = (g.max_batch * g.llm_heads >= gemm256_grid_cap() /* one attention workgroup per CU */ && (ctx->nsplit == 2 || ctx->nsplit == 4) && ctx->l_hd == 128 && ctx->attn_local) ? ctx->nsplit : 0;
     return at;
 }
 static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
