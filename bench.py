@@ -870,6 +870,7 @@ def main():
                 with torch.cuda.stream(sF):                        # captured on the stream that replays it, with the front end's GEMM grid (gemm_max_wgs)
                     fe["graph"] = FrontEndGraph(eng, G, F, v["image_size"], v["image_size"], r, plans[0], seq0=B, embeds=emb_all)
                     fe["graph"].launch()                           # first replay (uploads the graph) outside every timed interval
+                    fe["nodes"] = fe["graph"].nodes
                 sF.synchronize()
                 fe["capture_s"] = time.perf_counter() - t_cap
             pending[0] = front_async(0)
@@ -1121,7 +1122,7 @@ def main():
             "busiest_threads_note": "user + system seconds per cycle of the process's threads over the timed steps (/proc/self/task); the thread that is busy for the "
                                     "whole cycle is not Python's: the enqueue thread is the one marked (main), the two TTFT helpers and the power sampler follow",
             "gate_wait_s_per_cycle": (host_enq.get("gate_wait_s", 0.0) / host_enq["cycles"]) if host_enq["cycles"] else None,
-            "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe["graph"].nodes, "replays_per_cycle": NG,
+            "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe.get("nodes"), "replays_per_cycle": NG,
                            "capture_s": fe.get("capture_s"), "decode_graph_replays_per_cycle": S,
                            "eager_launches_per_cycle_besides": "per group: 4 input copies, 2 result copies, page-table swap + 4 resets + first-token kernels of the commit"}
                           if (continuous and overlap and fe["use"]) else ({"form": "eager launches"} if continuous else None)),
@@ -1391,6 +1392,9 @@ def main():
             assert int(lens_h[0]) == 1
         result["ttft_host_ms_single_clip"] = float(np.median(hl))
 
+    if continuous and overlap and fe.get("graph") is not None:
+        fe["graph"].eng = None                                     # the graph object holds the engine (and with it the 156 GB KV pool): the child runs below need the memory
+        fe["graph"] = None
     eng.close()
     del eng
     torch.cuda.empty_cache()
