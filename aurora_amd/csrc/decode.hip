@@ -404,7 +404,11 @@ __device__ __forceinline__ f4 ld_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
 
-template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
+// TPW (tiles per consumer wave; 2 only for the split-K residual projections on the half grid): a wave accumulates TWO consecutive tiles
+// against every x fragment it reads from LDS, so a workgroup owns 2 * T_MAX tiles per ring pass - on a stream that owns half of the CUs the
+// residual projections then run one round of 128 workgroups instead of two of 256, and x crosses a CU's LDS once instead of twice.  Every
+// tile keeps its k phases and its k order: bitwise the TPW == 1 result.
+template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL, int TPW = 1>
 __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(SkinnyArgs a, SkxGeom gm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];         // NBUF x KC x NB KiB ring, then 1/rms of every batch row
     constexpr int NCW = T_MAX * KS, Q = KC / KS;                        // consumer waves; steps per wave per chunk
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     static_assert((NBUF - 1) * PIECES <= 63, "vmcnt is a 6-bit counter");
     static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
     static_assert(MODE != SK_QKV || T_MAX % 3 == 0, "SK_QKV: a workgroup owns T_MAX / 3 units of one PAIRED block + one V tile");
+    static_assert(TPW == 1 || (TPW == 2 && MODE == SK_ROW && KS > 1), "two tiles per wave: split-K residual projections only");
     float* rstd_lds = (float*)(smem + NBUF * CHUNK_BYTES);              // [AUR_MAX_BATCH], written by loader wave 0 before the first barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,9 +482,9 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         tile = t < 2 * UN ? 2 * (c + (t >> 1) * (int)gridDim.x) + (t & 1) : gm.v_tile0 + c + (t - 2 * UN) * (int)gridDim.x;
     } else {
         ntile = gm.tiles_lo + (c < gm.n_hi ? 1 : 0);
-        tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + t;
+        tile = c * gm.tiles_lo + (c < gm.n_hi ? c : gm.n_hi) + TPW * t;
     }
-    if (t >= ntile) return;                                    // idle consumer (ended waves do not count at s_barrier)
+    if (TPW * t >= ntile) return;                              // idle consumer (ended waves do not count at s_barrier)
     // Epilogue waves.  SK_QKV spreads the RoPE / page-table / KV-store tail: the 2 * KS waves of a PAIRED block share its column
     // groups (NBPP each), the KS waves of a V tile theirs (NBPV each) - with one epilogue wave per tile 8 column groups serialised
     // behind the last MFMA (128 rows: 52.7 -> 36 us).  The other modes keep ONE epilogue wave per tile (k phase 0).
@@ -491,10 +496,13 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     const bool epi_wave = !split && (MODE == SK_QKV ? eg0 < NB : p == 0);
     SkPre<NBPV> pre;
     if (epi_wave) skinny_prefetch<MODE, NBPV, false>(a, lane, pre, tile, eg0);   // positions / page pointers (1/rms comes from LDS)
-    f4 acc[NB];
+    f4 acc[TPW][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[tp][nb] = f4{0.f, 0.f, 0.f, 0.f};
     const half_t* wbase = a.W + ((int64_t)tile * K32 + kb) * AUR_FRAG_HALVES + lane * 8;
+    const int64_t wtile = (int64_t)K32 * AUR_FRAG_HALVES;       // tile + 1 is K32 fragments further on
     const int NS = nchunk * Q;                                 // steps of this wave (the last chunk may hold invalid steps)
     // step j -> chunk j / Q, kk = (j % Q) * KS + p; k index clamped: an invalid step re-reads the last fragment against x = 0
     auto kof = [&](int j, bool& valid) {
@@ -502,15 +510,19 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
         valid = j < NS && kr < KE;
         return valid ? kr : KE - 1;
     };
-    h8 cw[U], nw[U];
+    h8 cw[U][TPW], nw[U][TPW];
     bool vv;
 #pragma unroll
-    for (int u = 0; u < U; ++u) cw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(u, vv) * AUR_FRAG_HALVES));
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) cw[u][tp] = __builtin_nontemporal_load((const h8*)(wbase + tp * wtile + (int64_t)kof(u, vv) * AUR_FRAG_HALVES));
     for (int j0 = 0; j0 < NS; j0 += U) {
         const bool more = j0 + U < NS;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nw[u] = __builtin_nontemporal_load((const h8*)(wbase + (int64_t)kof(j0 + U + u, vv) * AUR_FRAG_HALVES));
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int tp = 0; tp < TPW; ++tp) nw[u][tp] = __builtin_nontemporal_load((const h8*)(wbase + tp * wtile + (int64_t)kof(j0 + U + u, vv) * AUR_FRAG_HALVES));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -528,11 +540,15 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
                 for (int nb = 0; nb < NB; ++nb) xr[nb] = h8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(cw[u], xr[nb], acc[nb]);
+            for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[tp][nb] = mfma16(cw[u][tp], xr[nb], acc[tp][nb]);
         }
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) cw[u] = nw[u];
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int tp = 0; tp < TPW; ++tp) cw[u][tp] = nw[u][tp];
         }
     }
     const int N16 = a.Npad >> 4;
@@ -544,12 +560,38 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
             pr.rstd[nb] = b < AUR_MAX_BATCH ? rstd_lds[b] : 1.f;
         }
     };
+    if constexpr (TPW == 2) {
+        // two tiles per wave: the k phases of tile `tile + tp` meet in LDS one tile at a time (the scratch of one round fills the ring), phase
+        // order 0, 1, .. as ever; the split's partial goes to the reduce launch.  Every consumer wave passes every barrier.
+        float* red = (float*)smem;
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) {
+            SKX_BAR();                                         // x is read (round 0) / the previous round's scratch is read (round 1)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[tp][nb];
+            SKX_BAR();
+            if (p == 0 && TPW * t + tp < ntile) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f4 sum = *(const f4*)(red + ((w * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                    for (int pp = 1; pp < KS; ++pp) {
+                        const f4 q = *(const f4*)(red + (((w + pp) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum[i] += q[i];
+                    }
+                    *(f4*)(gm.part + ((((int64_t)s * (a.Npad >> 4) + tile + tp) * NB + nb) * 64 + lane) * 4) = sum;
+                }
+            }
+        }
+        return;
+    }
     // ---- K phases of a tile (and, for SK_QKV, the two tiles of a PAIRED block) meet in LDS; fixed summation order (phase 0, 1, ...)
     if (KS > 1 || MODE == SK_QKV) {
         SKX_BAR();                                             // every consumer is done reading x (the loaders have exited)
         float* red = (float*)smem;                             // [consumer wave][NB][64][4]  (<= 12 x 4 KiB: inside the ring)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[nb];
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(red + ((w * NB + nb) * 64 + lane) * 4) = acc[0][nb];
         SKX_BAR();
         if (!epi_wave && !split) return;
         if (split && gm.cnt == nullptr && p != 0) return;
@@ -656,12 +698,12 @@ __global__ __launch_bounds__(64 * (T_MAX * KS + NL)) void skinny_lds_kernel(Skin
     // KS == 1 (not SK_QKV): the wave holds the whole K sum of its tile and finishes it alone (NBPV == NB, eg0 == 0)
     if (split) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[nb];
+        for (int nb = 0; nb < NB; ++nb) *(f4*)(gm.part + ((((int64_t)s * N16 + tile) * NB + nb) * 64 + lane) * 4) = acc[0][nb];
         return;
     }
     f4 one[1][NBPV];
 #pragma unroll
-    for (int nb = 0; nb < NBPV; ++nb) one[0][nb] = acc[nb];
+    for (int nb = 0; nb < NBPV; ++nb) one[0][nb] = acc[0][nb];
     load_rstd(pre, 0);
     skinny_store<1, MODE, NBPV>(a, tile, one, lane, pre);
 }
@@ -689,19 +731,19 @@ __global__ __launch_bounds__(256) void skinny_row_reduce_kernel(SkinnyArgs a, Sk
 
 static int g_skx_cus = 256;
 
-template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL>
+template <int T_MAX, int KS, int MODE, int NB, int KC, int NBUF, int U, int NL, int TPW = 1>
 static hipError_t launch_skx_t(const SkinnyArgs& a, const SkxGeom& gm, dim3 grid, hipStream_t s) {
     constexpr int ring = NBUF * KC * NB * 1024;
     constexpr int lds = ring + AUR_MAX_BATCH * 4 + 64;         // + 1/rms per batch row + the fused split-K reduce's "last split" flags
     static_assert(ring >= T_MAX * KS * NB * 1024, "the reduction scratch lives inside the x ring");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL>,
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL, TPW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL>), grid, dim3(64 * (T_MAX * KS + NL)), lds, s, a, gm);
+    hipLaunchKernelGGL((skinny_lds_kernel<T_MAX, KS, MODE, NB, KC, NBUF, U, NL, TPW>), grid, dim3(64 * (T_MAX * KS + NL)), lds, s, a, gm);
     return hipGetLastError();
 }
 
@@ -767,6 +809,17 @@ static hipError_t launch_skx_nb(const SkinnyArgs& a, float* part, hipStream_t s)
             // there, o 18.9 -> 18.0 us, down 31.5 -> 29.4 us incl. the reduce, but neutral in the engine - 19.3 / 30.1 us either way - and
             // rocprofv3's counter mode crashed in this launch with that instantiation: kept as it was)
             gm.cnt = a.row_cnt;
+            if constexpr (NB > 4) {
+                // half grid (a stream that owns half of the CUs): 8 tiles per workgroup, two per wave - one round of N16 / 8 x 4 workgroups;
+                // same k phases and k order per tile: bitwise the full grid's partials.  (The in-kernel reduce keeps the full grid.)
+                if (half && gm.cnt == nullptr && (N16 & 7) == 0) {
+                    gm.tiles_lo = 8;
+                    hipError_t e2 = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 1, NLR, 2>(a, gm, dim3(N16 / 8, 4), s);      // U = 1: two tiles x (current + next) fragments = the full-grid form's bytes in flight, and 128 registers without a spill
+                    if (e2 != hipSuccess) return e2;
+                    hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);
+                    return hipGetLastError();
+                }
+            }
             hipError_t e = launch_skx_t<4, 3, SK_ROW, NB, KCR, NBUFR, 2, NLR>(a, gm, dim3(N16 / 4, 4), s);
             if (e != hipSuccess || gm.cnt != nullptr) return e;
             hipLaunchKernelGGL(skinny_row_reduce_kernel, dim3((N16 * NB + 3) / 4), dim3(256), 0, s, a, gm, NB);

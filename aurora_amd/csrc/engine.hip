@@ -1187,7 +1187,7 @@ static SkinnyArgs mk_dec_o(aur_ctx* ctx, int l) {
     o.xf = ctx->d_attn; o.W = ctx->ll[l].o_w; o.B = ctx->batch; o.b_lo = 0; o.b_hi = ctx->batch; o.Npad = ctx->l_dpad; o.K = d; o.n_real = d;
     o.mode = SK_ROW; o.xres = ctx->d_x; o.ssq_out = ctx->s_ssq_attn;
     o.variant = ctx->skinny_variant; o.part = (d >= ctx->row_split_min_k || ctx->cfg.max_batch > 64) ? ctx->d_part_row : nullptr;
-    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
+    o.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; o.half_grid = ctx->decode_half;
     return o;
 }
 static SkinnyArgs mk_dec_gateup(aur_ctx* ctx, int l) {
@@ -1207,7 +1207,7 @@ static SkinnyArgs mk_dec_down(aur_ctx* ctx, int l) {
     dn.xf = ctx->d_h; dn.W = ctx->ll[l].down_w; dn.B = ctx->batch; dn.b_lo = 0; dn.b_hi = ctx->batch; dn.Npad = ctx->l_dpad; dn.K = g.llm_mlp;
     dn.n_real = d; dn.mode = SK_ROW; dn.xres = ctx->d_x; dn.ssq_out = ctx->s_ssq_mlp;
     dn.variant = ctx->skinny_variant; dn.part = (g.llm_mlp >= ctx->row_split_min_k || g.max_batch > 64) ? ctx->d_part_row : nullptr;
-    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr;
+    dn.row_cnt = ctx->fused_reduce ? ctx->d_row_cnt : nullptr; dn.half_grid = ctx->decode_half;
     return dn;
 }
 
