@@ -196,3 +196,47 @@ extern "C" int lab_kvwork_launch(void* stream, const void* pool, int slots, int 
     hipLaunchKernelGGL(lab_kvwork_kernel, dim3(1, 32, slots), dim3(64), 0, (hipStream_t)stream, (const lh8*)pool, pages_per_slot, work, sink);
     return (int)hipGetLastError();
 }
+
+
+// ---- the same KV walk through LDS-DMA (round 6): is what a CU keeps in flight on half of the chip (~47 GB/s per CU for register loads)
+// a limit of the register-return path, or of the CU's memory pipeline whatever the destination?  One workgroup = WAVES waves, each walking its
+// own (slot, head); a wave owns a ring of two 16 KiB halves in LDS and keeps up to 32 one-KiB `global_load_lds` pieces in flight (counted
+// vmcnt), consuming nothing.  Same bytes, same addresses as lab_kvpattern_kernel mode 0.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lab_kvpattern_lds_kernel(const f4v* __restrict__ pool, int pages_per_slot, int heads, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pair = blockIdx.x * WAVES + w;                       // (slot, head)
+    const int head = pair % heads, slot = pair / heads;
+    char* ring = lsm + w * 32768;
+    auto issue = [&](int p, int part) {
+        const f4v* src = pool + ((int64_t)slot * pages_per_slot + p) * 65536 + (int64_t)part * 32768 + head * 1024 + lane;
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64),
+                                             (__attribute__((address_space(3))) void*)(ring + part * 16384 + f * 1024), 16, 0, 2);
+    };
+    issue(0, 0);
+    issue(0, 1);
+    for (int p = 1; p < pages_per_slot; ++p) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // the K half of page p - 1 has landed: its ring half is free
+        issue(p, 0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        issue(p, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pages_per_slot < 0) sink[0] = *(float*)ring;
+}
+extern "C" int lab_kvpattern_lds_launch(void* stream, const void* pool, int slots, int pages_per_slot, int waves, float* sink) {
+    const int pairs = slots * 32;
+    if (waves == 4) {
+        static bool set4 = false;
+        if (!set4) { (void)hipFuncSetAttribute((const void*)lab_kvpattern_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768); set4 = true; }
+        hipLaunchKernelGGL(lab_kvpattern_lds_kernel<4>, dim3(pairs / 4), dim3(256), 4 * 32768, (hipStream_t)stream, (const f4v*)pool, pages_per_slot, 32, sink);
+    } else if (waves == 2) {
+        hipLaunchKernelGGL(lab_kvpattern_lds_kernel<2>, dim3(pairs / 2), dim3(128), 2 * 32768, (hipStream_t)stream, (const f4v*)pool, pages_per_slot, 32, sink);
+    } else {
+        hipLaunchKernelGGL(lab_kvpattern_lds_kernel<1>, dim3(pairs), dim3(64), 32768, (hipStream_t)stream, (const f4v*)pool, pages_per_slot, 32, sink);
+    }
+    return (int)hipGetLastError();
+}
