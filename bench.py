@@ -867,12 +867,16 @@ def main():
             if args.front_graph:
                 from aurora_amd.engine import FrontEndGraph
                 t_cap = time.perf_counter()
-                with torch.cuda.stream(sF):                        # captured on the stream that replays it, with the front end's GEMM grid (gemm_max_wgs)
-                    fe["graph"] = FrontEndGraph(eng, G, F, v["image_size"], v["image_size"], r, plans[0], seq0=B, embeds=emb_all)
-                    fe["graph"].launch()                           # first replay (uploads the graph) outside every timed interval
-                    fe["nodes"] = fe["graph"].nodes
-                sF.synchronize()
-                fe["capture_s"] = time.perf_counter() - t_cap
+                try:
+                    with torch.cuda.stream(sF):                    # captured on the stream that replays it, with the front end's GEMM grid (gemm_max_wgs)
+                        fe["graph"] = FrontEndGraph(eng, G, F, v["image_size"], v["image_size"], r, plans[0], seq0=B, embeds=emb_all)
+                        fe["graph"].launch()                       # first replay (uploads the graph) outside every timed interval
+                        fe["nodes"] = fe["graph"].nodes
+                    sF.synchronize()
+                    fe["capture_s"] = time.perf_counter() - t_cap
+                except Exception as ex:                            # noqa: BLE001 - a runtime that cannot capture: the line still gets measured, eagerly
+                    print(f"bench.py: front-end graph capture failed ({ex!r}); front ends are enqueued eagerly", file=sys.stderr)
+                    fe["graph"], fe["capture_error"] = None, repr(ex)
             pending[0] = front_async(0)
             k_cal["on"] = args.overlap_steps < 0 and sDm is not None      # measured during the warm-up cycle(s) below, applied after them
         n_warm = max(args.warmup - 1, 1 if overlap else 0)          # overlap: the first front end above overlapped nothing
@@ -1125,7 +1129,7 @@ def main():
             "front_end": ({"form": "hipGraph replay per group (engine.FrontEndGraph)", "graph_nodes": fe.get("nodes"), "replays_per_cycle": NG,
                            "capture_s": fe.get("capture_s"), "decode_graph_replays_per_cycle": S,
                            "eager_launches_per_cycle_besides": "per group: 4 input copies, 2 result copies, page-table swap + 4 resets + first-token kernels of the commit"}
-                          if (continuous and overlap and fe["use"]) else ({"form": "eager launches"} if continuous else None)),
+                          if (continuous and overlap and fe["use"]) else ({"form": "eager launches", "capture_error": (fe.get("capture_error") if (continuous and overlap) else None)} if continuous else None)),
             "cores_allowed": len(aff), "pinned_to_gpu_numa_cores": pinned,
             "note": "enqueue = host wall time of the Python thread that issues a cycle's launches, up to (not including) the blocking read-back of "
                     "the ids; process_cpu = user + system seconds of the whole process (enqueue thread, the two TTFT helper threads, the power sampler) "
