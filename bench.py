@@ -128,10 +128,11 @@ def parse():
     p.add_argument("--front-graph", type=int, default=1, choices=[0, 1],
                    help="overlapped schedule: 1 (default) = a group's front end (ViT + ToMe + projector / splice + staged prefill) is ONE captured hipGraph "
                         "(engine.FrontEndGraph: inputs copied into static buffers, one replay per group); 0 = ~500 eager launches per group.  Same ids")
-    p.add_argument("--ttft-gate-steps", type=int, default=0,
-                   help="overlapped schedule: bounded run-ahead - the host submits a group's front end only when the device is within this many + 1 decode "
-                        "steps of the point where that front end may start, so that the host-observed submit -> first-token time stays close to the "
-                        "device interval; -1 = unbounded (rounds 2-5: the enqueue thread ran > 1 s ahead)")
+    p.add_argument("--ttft-gate-steps", type=int, default=1,
+                   help="overlapped schedule: bounded run-ahead - the host submits a group's front end only when the device is within this many decode "
+                        "steps of the point where that front end may start (0 = at that point: the front end then starts a host round trip late), so that "
+                        "the host-observed submit -> first-token time stays close to the device interval; -1 = unbounded (rounds 2-5: the enqueue "
+                        "thread ran > 1 s ahead)")
     p.add_argument("--no-stamps", action="store_true", help="do not stamp the decode attention of one layer inside the captured step (roofline.frac_in_timed_loop)")
     p.add_argument("--ttft-delay-steps", type=int, default=-1, help="overlapped schedule: the front end of a group starts this many decode steps after the previous "
                    "boundary instead of at it (-1 = calibrated in the warm-up cycle so that it finishes just before its own boundary: no commit wait)")
@@ -769,11 +770,11 @@ def main():
                     n, k1, lead = chunk_plan(g)
                     rest = n - k1 - lead
                     # bounded run-ahead (TTFT runs from the SUBMISSION of a request).  The front end of group g + 1 may start after
-                    # `lead` steps of this chunk; the host submits it when the device is `margin` = --ttft-gate-steps + 1 steps before that
+                    # `lead` steps of this chunk; the host submits it when the device is `margin` = --ttft-gate-steps steps before that
                     # point - an event recorded inside this chunk's lead segment, or (lead < margin) inside the PREVIOUS chunk's tail - and
                     # never earlier.  The decode replays themselves are enqueued at most three blocks of 8 steps ahead of the device (the
                     # enqueue thread sleeps instead of spinning in the runtime's back-pressure: cfg5's chunks are 170 steps long).
-                    margin = max(0, args.ttft_gate_steps) + 1
+                    margin = max(0, args.ttft_gate_steps)
                     marks = {}                                             # steps of this chunk enqueued -> record an event on the current stream
                     gate_in = [None]
                     if gate_on and lead - margin >= 0:
@@ -1089,7 +1090,7 @@ def main():
             "p50_ttft_ms": (float(np.median(submit_ttft)) if (continuous and overlap and gate_on and submit_ttft) else (float(np.median(ttft_ms)) if ttft_ms else None)),
             "p50_ttft_definition": ("host clock: submission of a group's front end (host call) -> its first token ids in pinned host memory; the host submits a "
                                     "front end only when the device is within %d decode step(s) of the point where that front end may start (bounded run-ahead)"
-                                    % (max(args.ttft_gate_steps, 0) + 1)) if (continuous and overlap and gate_on and submit_ttft) else "device-event interval (see ttft_note)",
+                                    % max(args.ttft_gate_steps, 0)) if (continuous and overlap and gate_on and submit_ttft) else "device-event interval (see ttft_note)",
             "p50_ttft_device_ms": float(np.median(ttft_ms)) if ttft_ms else None,
             "p90_ttft_ms": (float(np.percentile(submit_ttft, 90)) if (continuous and overlap and gate_on and submit_ttft) else None),
             "power": power, "power_sampling": ("off" if not (rank == 0 and want_power) else (power or {}).get("how", "no samples")),
