@@ -367,6 +367,16 @@ def sleep_wait(ev, dt: float = 0.0005):
         time.sleep(dt)
 
 
+def gate_positions(n: int, lead: int, lead_next: int, margin: int):
+    """Where a chunk of `n` decode steps records the two events of the bounded run-ahead (positions = steps of the chunk enqueued so far):
+    `pos_in` - the host may submit THIS chunk's front end (it may start after `lead` steps) once the device is `margin` steps before that
+    point, if that point lies inside this chunk (else None: the previous chunk's tail event is the gate); `pos_tail` - the event the NEXT
+    chunk needs when its own start point is less than `margin` steps into it (else None)."""
+    pos_in = lead - margin if lead - margin >= 0 else None
+    pos_tail = max(n - (margin - lead_next), 0) if lead_next - margin < 0 else None
+    return pos_in, pos_tail
+
+
 def masked_steps_per_chunk(front_ms: float, step_ms: float, chunk_steps: int) -> int:
     """Decode steps of a chunk that run on the decode mask: as many as the front end lasts beside them (both measured in the warm-up
     cycle), at most the chunk's whole steps, at least one."""
@@ -776,15 +786,14 @@ def main():
                     # never earlier.  The decode replays themselves are enqueued at most three blocks of 8 steps ahead of the device (the
                     # enqueue thread sleeps instead of spinning in the runtime's back-pressure: cfg5's chunks are 170 steps long).
                     margin = max(0, args.ttft_gate_steps)
-                    marks = {}                                             # steps of this chunk enqueued -> record an event on the current stream
-                    gate_in = [None]
-                    if gate_on and lead - margin >= 0:
-                        marks[lead - margin] = lambda: gate_in.__setitem__(0, _record())
-                    tail = [None]
+                    marks = {}                                             # steps of this chunk enqueued -> events to record there, on the current stream
+                    gate_in, tail = [None], [None]
                     if gate_on:
-                        _, _, lead_nx = chunk_plan((g + 1) % NG)
-                        if lead_nx - margin < 0:                            # the next iteration's gate lies in this chunk's tail
-                            marks[max(n - (margin - lead_nx), 0)] = lambda: tail.__setitem__(0, _record())
+                        pos_in, pos_tail = gate_positions(n, lead, chunk_plan((g + 1) % NG)[2], margin)
+                        if pos_in is not None:
+                            marks.setdefault(pos_in, []).append(lambda: gate_in.__setitem__(0, _record()))
+                        if pos_tail is not None:
+                            marks.setdefault(pos_tail, []).append(lambda: tail.__setitem__(0, _record()))
 
                     def _record():
                         ev_ = torch.cuda.Event()
@@ -794,8 +803,8 @@ def main():
                     def decode_seg(steps, base):
                         i_ = 0
                         while True:
-                            if base + i_ in marks:
-                                marks.pop(base + i_)()
+                            for fn_ in marks.pop(base + i_, ()):
+                                fn_()
                             if i_ >= steps:
                                 break
                             stops = [m - base for m in marks if base + i_ < m <= base + steps] + [steps] + ([i_ + 8] if gate_on else [])
@@ -812,8 +821,9 @@ def main():
                         decode_seg(lead, 0)
                         go = torch.cuda.Event()
                         go.record(sD)
-                    elif 0 in marks:
-                        marks.pop(0)()                                      # lead == 0: a mark at the chunk's start sits right behind the commit
+                    else:
+                        for fn_ in marks.pop(0, ()):                        # lead == 0: a mark at the chunk's start sits right behind the commit
+                            fn_()
                     sF.wait_event(go)
                     gate = gate_in[0] if gate_in[0] is not None else gate_prev[0]
                     if gate_on and gate is not None:

@@ -324,3 +324,26 @@ def test_bench_child_point_reads_the_last_json_line_and_survives_failures(tmp_pa
     monkeypatch.setattr(subprocess, "run", boom)
     assert bench.child_point(["--batch", "1"]) is None
     assert bench.masked_steps_per_chunk(240.0, 36.7, 8) == 7 and bench.masked_steps_per_chunk(10.0, 36.7, 8) == 1 and bench.masked_steps_per_chunk(900.0, 36.7, 8) == 8
+
+
+def test_bench_gate_positions_bound_the_run_ahead():
+    """bench.gate_positions: the host submits a front end `margin` decode steps before the point where it may start - inside the chunk's
+    leading steps when that point is deep enough, otherwise in the previous chunk's tail; never outside [0, n]."""
+    import bench
+    # cfg2: chunks of 8 steps, 7 masked -> the front end may start after 1 leading step
+    assert bench.gate_positions(8, 1, 1, 0) == (1, None)          # margin 0: at the start point itself
+    assert bench.gate_positions(8, 1, 1, 1) == (0, None)          # one step earlier = right behind the commit
+    assert bench.gate_positions(8, 1, 1, 2) == (None, 7)          # two steps: one step before the end of the previous chunk
+    assert bench.gate_positions(8, 0, 0, 0) == (0, None)          # no leading step: behind the commit
+    assert bench.gate_positions(8, 0, 0, 1) == (None, 7)
+    # cfg5: 170-step chunks, the front end starts after 150 leading steps
+    assert bench.gate_positions(170, 150, 150, 0) == (150, None)
+    assert bench.gate_positions(170, 150, 150, 3) == (147, None)
+    for n in range(1, 12):
+        for lead in range(0, n + 1):
+            for lead_next in range(0, n + 1):
+                for margin in range(0, 14):
+                    pi, pt = bench.gate_positions(n, lead, lead_next, margin)
+                    assert pi is None or 0 <= pi <= lead
+                    assert pt is None or 0 <= pt <= n
+                    assert (pi is None) == (lead < margin) and (pt is None) == (lead_next >= margin)
